@@ -1,0 +1,198 @@
+"""PyTorch-CPU fp32 restatement of the reference's Darknet graph (TEST INFRASTRUCTURE ONLY).
+
+Follows ``models.py:16-83`` (cfg blocks -> layers), ``models.py:237-255``
+(interpreter), ``models.py:127-222`` (YOLO decode + loss) and
+``models.py:257-308`` (Darknet ``.weights`` layout) of the reference.  The
+convolution / batch-norm arithmetic itself is PyTorch ATen on the CPU, exactly
+what the reference dispatches to (SURVEY.md §8c "third-party arithmetic").
+
+``mode="bf16"`` emulates the numeric contract of the HIP bf16 path so layer
+outputs can be compared tightly: conv operands rounded to bfloat16, fp32
+accumulation, fp32 BN-affine + LeakyReLU (+ residual) epilogue, ONE rounding to
+bfloat16 per stored activation; the stem (fp32 image in) and the three linear
+heads (fp32 out) are not rounded.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def parse_cfg(path):
+    """utils/parse_config.py:3-21 (own restatement; values stay strings)."""
+    blocks = []
+    for raw in open(path).read().split("\n"):
+        line = raw.strip()
+        if not line or line.startswith("#"):
+            continue
+        if line.startswith("["):
+            blocks.append({"type": line[1:-1].rstrip()})
+            if blocks[-1]["type"] == "convolutional":
+                blocks[-1]["batch_normalize"] = 0
+        else:
+            k, v = line.split("=")
+            blocks[-1][k.rstrip()] = v.strip()
+    return blocks
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class OracleDarknet:
+    def __init__(self, cfg_path):
+        defs = parse_cfg(cfg_path)
+        self.hyper = defs[0]
+        self.defs = defs[1:]
+        self.params = {}  # layer idx -> dict of torch tensors
+        filters = [int(self.hyper["channels"])]
+        for i, d in enumerate(self.defs):
+            t = d["type"]
+            if t == "convolutional":
+                cin, cout, k = filters[-1], int(d["filters"]), int(d["size"])
+                p = {"weight": torch.zeros(cout, cin, k, k)}
+                if int(d["batch_normalize"]):
+                    p.update(gamma=torch.ones(cout), beta=torch.zeros(cout), mean=torch.zeros(cout), var=torch.ones(cout))
+                else:
+                    p["bias"] = torch.zeros(cout)
+                self.params[i] = p
+                f = cout
+            elif t == "route":
+                f = sum(filters[1:][int(x)] for x in d["layers"].split(","))
+            elif t == "shortcut":
+                f = filters[1:][int(d["from"])]
+            else:
+                f = filters[-1]
+            filters.append(f)
+        self.seen = 0
+        self.metrics = []
+
+    # ---- weights (models.py:257-308) -------------------------------------------------
+    def load_darknet_weights(self, path):
+        with open(path, "rb") as fh:
+            header = np.fromfile(fh, dtype=np.int32, count=5)
+            w = np.fromfile(fh, dtype=np.float32)
+        self.seen = int(header[3])
+        ptr = 0
+        for i, d in enumerate(self.defs):
+            if d["type"] != "convolutional":
+                continue
+            p = self.params[i]
+            names = ("beta", "gamma", "mean", "var") if int(d["batch_normalize"]) else ("bias",)
+            for n in names + ("weight",):
+                cnt = p[n].numel()
+                p[n] = torch.from_numpy(w[ptr:ptr + cnt].copy()).view_as(p[n])
+                ptr += cnt
+        assert ptr == w.size, (ptr, w.size)
+
+    def set_params(self, params):
+        for i, p in params.items():
+            for k, v in p.items():
+                self.params[i][k] = torch.from_numpy(np.ascontiguousarray(v, np.float32)).clone()
+
+    def require_grad(self):
+        for p in self.params.values():
+            for k in ("weight", "gamma", "beta", "bias"):
+                if k in p:
+                    p[k] = p[k].detach().clone().requires_grad_(True)
+
+    # ---- forward ----------------------------------------------------------------------
+    def _conv_block(self, i, d, x, mode, train_bn):
+        p = self.params[i]
+        k, s = int(d["size"]), int(d["stride"])
+        w = p["weight"]
+        first = x.shape[1] == int(self.hyper["channels"]) and i == 0
+        if mode == "bf16" and not first:
+            w = _bf16(w)
+        y = F.conv2d(x, w, None, stride=s, padding=(k - 1) // 2)
+        if int(d["batch_normalize"]):
+            if train_bn:
+                # models.py:43 -- PyTorch momentum 0.9 semantics
+                y = F.batch_norm(y, p["mean"], p["var"], p["gamma"], p["beta"], True, 0.9, 1e-5)
+            else:
+                scale = p["gamma"] / torch.sqrt(p["var"] + 1e-5)
+                shift = p["beta"] - p["mean"] * scale
+                y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        else:
+            y = y + p["bias"].view(1, -1, 1, 1)
+        if d["activation"] == "leaky":
+            y = F.leaky_relu(y, 0.1)
+        return y
+
+    def forward(self, x, targets=None, mode="fp32", train_bn=False, collect=False):
+        """x [B,3,S,S] float32 tensor.  Returns outputs [B,N,5+C] (and loss if targets)."""
+        img_dim = x.shape[2]
+        outs_r, outs_f = [], []  # stored (rounded) and unrounded fp32 value of every layer output
+        yolo_out, loss = [], 0
+        self.metrics = []
+        rnd = _bf16 if mode == "bf16" else (lambda t: t)
+        for i, d in enumerate(self.defs):
+            t = d["type"]
+            if t == "convolutional":
+                xf = self._conv_block(i, d, x, mode, train_bn)
+                is_head = not int(d["batch_normalize"])
+                x = xf if is_head else rnd(xf)
+            elif t == "upsample":
+                xf = x = F.interpolate(x, scale_factor=int(d["stride"]), mode="nearest")
+            elif t == "route":
+                xf = x = torch.cat([outs_r[int(j)] for j in d["layers"].split(",")], 1)
+            elif t == "shortcut":
+                xf = outs_f[-1] + outs_r[int(d["from"])]
+                x = rnd(xf)
+            elif t == "yolo":
+                x, layer_loss = self._yolo(d, x, targets, img_dim)
+                xf = x
+                loss = loss + layer_loss
+                yolo_out.append(x)
+            outs_r.append(x)
+            outs_f.append(xf)
+        self.layer_outputs = outs_r if collect else None
+        out = torch.cat(yolo_out, 1).detach()
+        return out if targets is None else (loss, out)
+
+    def _yolo(self, d, x, targets, img_dim):
+        """models.py:127-222."""
+        mask = [int(v) for v in d["mask"].split(",")]
+        a = [int(v) for v in d["anchors"].split(",")]
+        anchors = [(a[2 * m], a[2 * m + 1]) for m in mask]
+        C = int(d["classes"])
+        B, _, G, _ = x.shape
+        A = len(anchors)
+        pred = x.view(B, A, C + 5, G, G).permute(0, 1, 3, 4, 2).contiguous()
+        sx, sy = torch.sigmoid(pred[..., 0]), torch.sigmoid(pred[..., 1])
+        w, h = pred[..., 2], pred[..., 3]
+        conf, cls = torch.sigmoid(pred[..., 4]), torch.sigmoid(pred[..., 5:])
+        stride = img_dim / G
+        gx = torch.arange(G, dtype=torch.float32).repeat(G, 1).view(1, 1, G, G)
+        gy = torch.arange(G, dtype=torch.float32).repeat(G, 1).t().view(1, 1, G, G)
+        sa = torch.tensor([(aw / stride, ah / stride) for aw, ah in anchors], dtype=torch.float32)
+        boxes = torch.empty(pred[..., :4].shape)
+        boxes[..., 0] = sx.detach() + gx
+        boxes[..., 1] = sy.detach() + gy
+        boxes[..., 2] = torch.exp(w.detach()) * sa[:, 0].view(1, A, 1, 1)
+        boxes[..., 3] = torch.exp(h.detach()) * sa[:, 1].view(1, A, 1, 1)
+        out = torch.cat((boxes.view(B, -1, 4) * stride, conf.view(B, -1, 1), cls.view(B, -1, C)), -1)
+        if targets is None:
+            return out, 0
+        from . import boxes_oracle as bo
+        tg = bo.build_targets(boxes.numpy(), cls.detach().numpy(), targets.numpy(), sa.numpy(), 0.5)
+        iou_scores, class_mask, obj, noobj, tx, ty, tw, th, tcls, tconf = [torch.from_numpy(np.ascontiguousarray(v)) for v in tg]
+        mse, bce = F.mse_loss, F.binary_cross_entropy
+        lx, ly = mse(sx[obj], tx[obj]), mse(sy[obj], ty[obj])
+        lw, lh = mse(w[obj], tw[obj]), mse(h[obj], th[obj])
+        lconf_obj = bce(conf[obj], tconf[obj])
+        lconf_noobj = bce(conf[noobj], tconf[noobj])
+        lconf = 1 * lconf_obj + 100 * lconf_noobj
+        lcls = bce(cls[obj], tcls[obj])
+        total = lx + ly + lw + lh + lconf + lcls
+        conf50 = (conf > 0.5).float()
+        iou50, iou75 = (iou_scores > 0.5).float(), (iou_scores > 0.75).float()
+        det = conf50 * class_mask
+        self.metrics.append({
+            "loss": total.item(), "x": lx.item(), "y": ly.item(), "w": lw.item(), "h": lh.item(),
+            "conf": lconf.item(), "cls": lcls.item(), "cls_acc": (100 * class_mask[obj].mean()).item(),
+            "recall50": (torch.sum(iou50 * det) / (obj.sum() + 1e-16)).item(),
+            "recall75": (torch.sum(iou75 * det) / (obj.sum() + 1e-16)).item(),
+            "precision": (torch.sum(iou50 * det) / (conf50.sum() + 1e-16)).item(),
+            "conf_obj": conf[obj].mean().item(), "conf_noobj": conf[noobj].mean().item(), "grid_size": G,
+        })
+        return out, total
