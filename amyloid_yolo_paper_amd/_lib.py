@@ -1,0 +1,82 @@
+"""ctypes binding of libamyloid_yolo_hip.so (the C ABI declared in include/amyloid_yolo.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libamyloid_yolo_hip.so")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "cin", "cout", "hin", "win", "hout", "wout", "ksize", "stride", "leaky", "out_f32", "cout_pad")]
+
+
+class AyError(RuntimeError):
+    pass
+
+
+_P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+_SIGS = {
+    "ay_version": (C.c_int, []),
+    "ay_last_error": (C.c_char_p, []),
+    "ay_pack_conv_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_packed_weight_bytes": (_SZ, [_I, _I, _I]),
+    "ay_fold_bn": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P]),
+    "ay_stem_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_conv_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ay_concat_upsample_bf16": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "ay_blocked_bf16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_blocked_f32_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_nchw_f32_to_blocked_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_conv_fwd_f32": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ay_yolo_decode": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _P]),
+    "ay_xywh2xyxy": (_I, [_P, _I64, _I, _P]),
+    "ay_box_iou": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
+    "ay_box_iou_pairwise": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "ay_nms_workspace_bytes": (_SZ, [_I, _I]),
+    "ay_nms_filter": (_I, [_P, _I, _I, _I, _F, _P, _P, _SZ, _P]),
+    "ay_nms_sort_merge": (_I, [_P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """The loaded library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AyError(
+                f"{LIB_PATH} is missing: build it with `python -m amyloid_yolo_paper_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ay_last_error()
+        raise AyError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor, None -> NULL"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

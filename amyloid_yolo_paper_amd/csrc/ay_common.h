@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of libamyloid_yolo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/amyloid_yolo.h"
+
+namespace ay {
+
+void set_error(const char* fmt, ...);
+
+#define AY_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            ay::set_error(__VA_ARGS__);  \
+            return AY_ERR_ARG;           \
+        }                                \
+    } while (0)
+
+#define AY_CHECK_LAUNCH(what)                                                      \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ay::set_error("%s: %s", what, hipGetErrorString(e_));                  \
+            return AY_ERR_LAUNCH;                                                  \
+        }                                                                          \
+    } while (0)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// round-to-nearest-even f32 -> bf16 bits (plain cast: keeps NaN a NaN, v_cvt_pk_bf16_f32 at -O3)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) {
+    return __builtin_bit_cast(float, (uint32_t)u << 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+static inline hipStream_t S(ay_stream_t s) { return (hipStream_t)s; }
+
+}  // namespace ay

@@ -1,0 +1,351 @@
+// Direct (im2col-free) convolution for gfx950: blocked-bf16 activations, MFMA 32x32x16 bf16, fp32
+// accumulate, LDS-staged input halo tile + filter slab, fused BN-affine + LeakyReLU + residual epilogue.
+//
+// Replaces the cuDNN/ATen conv + BatchNorm2d + LeakyReLU (+ shortcut add) sequence the reference runs
+// per block (models.py:26-45 executed at models.py:242-248).
+//
+// GEMM view (per image):  D[cout][pixel] = sum_{tap, cin} W[cout][tap][cin] * X[cin][pixel + tap]
+//   A operand = filters  (rows = output channels), B operand = input pixels (cols), K = 16 input
+//   channels of one filter tap per MFMA.  A workgroup owns BN output channels x (TH x TW) output pixels
+//   of one image; per 16-channel input chunk it stages the (TH*s+2)x(TW*s+2) input halo tile ONCE and
+//   re-reads it from LDS for all 9 taps (tap shift = immediate offset on the ds_read), so global->LDS
+//   traffic for the input is ~1.3x instead of 9x.
+//
+// Layouts
+//   activations  [B][C/16][H][W][16] bf16     ("c16 planes": one chunk of one tile row is contiguous)
+//   weights      [Cin/16][tap][half][CoutPad][8] bf16   (half = input channels 0-7 / 8-15 of the chunk)
+//   LDS pixels   [kstep][half][IN_PIX][8 bf16]  -> lane (pixel c, half h) reads 16 B, conflict-free
+//   LDS filters  [kstep][tap][half][BN][8 bf16]
+#include "ay_common.h"
+
+namespace ay {
+
+struct ConvArgs {
+    const uint8_t* src;
+    const uint8_t* w;
+    const float* scale;
+    const float* shift;
+    const uint8_t* residual;
+    uint8_t* out;
+    int batch, cin, cout_pad, hin, win, hout, wout;
+    int tiles_x, tiles_y, n_cgroups;
+    int leaky;
+};
+
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
+__global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int KK2 = KS * KS;
+    constexpr int NPIX = TH * TW;
+    constexpr int NT = NPIX / (WN * 32);  // 32-pixel column blocks per wave
+    constexpr int MT = BN / (WM * 32);    // 32-channel row blocks per wave
+    constexpr int IN_H = (TH - 1) * STRIDE + KS;
+    constexpr int IN_W = (TW - 1) * STRIDE + KS;
+    constexpr int IN_PIX = IN_H * IN_W;
+    constexpr int PIX_SLAB = 2 * IN_PIX * 16;
+    constexpr int W_SLAB = KK2 * 2 * BN * 16;
+    constexpr int W_BASE = NK * PIX_SLAB;
+    constexpr int LDS_BYTES = NK * (PIX_SLAB + W_SLAB);
+    constexpr int PXU_TOTAL = NK * 2 * IN_PIX;
+    constexpr int NPXU = (PXU_TOTAL + 255) / 256;
+    constexpr int WU_TOTAL = NK * KK2 * 2 * BN;
+    constexpr int NWU = (WU_TOTAL + 255) / 256;
+    static_assert(WM * WN == 4 && NT >= 1 && MT >= 1, "4 waves");
+    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int c = lane & 31, hh = lane >> 5;
+
+    // workgroup -> (image, pixel tile, channel group); channel groups of one pixel tile are adjacent
+    // so they hit the same staged input in L2.
+    const int bid = blockIdx.x;
+    const int cg = bid % a.n_cgroups;
+    const int pt = bid / a.n_cgroups;
+    const int tile_x = pt % a.tiles_x;
+    const int tile_y = (pt / a.tiles_x) % a.tiles_y;
+    const int b = pt / (a.tiles_x * a.tiles_y);
+    const int y0 = tile_y * TH, x0 = tile_x * TW;
+
+    const size_t in_plane = (size_t)a.hin * a.win * 32;
+    const uint8_t* src_img = a.src + (size_t)b * (a.cin / 16) * in_plane;
+    const int CP = a.cout_pad;
+    const uint8_t* wbase = a.w + (size_t)cg * BN * 16;
+    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
+
+    // ---- per-thread staging map (fixed for the whole K loop) --------------------------------
+    int px_off[NPXU];
+#pragma unroll
+    for (int i = 0; i < NPXU; ++i) {
+        const int u = i * 256 + tid;
+        int off = -1;
+        if (u < PXU_TOTAL) {
+            const int kk = u / (2 * IN_PIX);
+            const int v = u % (2 * IN_PIX);
+            const int P = v >> 1, h = v & 1;
+            const int iy = y0 * STRIDE - PAD + P / IN_W;
+            const int ix = x0 * STRIDE - PAD + P % IN_W;
+            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+        }
+        px_off[i] = off;
+    }
+
+    uint4 rpx[NPXU];
+    uint4 rw[NWU];
+
+    auto issue = [&](int s) {
+        const uint8_t* sp = src_img + (size_t)s * NK * in_plane;
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (px_off[i] >= 0) v = *reinterpret_cast<const uint4*>(sp + px_off[i]);
+            rpx[i] = v;
+        }
+        const uint8_t* wp = wbase + (size_t)s * w_stage_stride;
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int u = i * 256 + tid;
+            if (u < WU_TOTAL) {
+                const int r = u % BN;
+                const int th = u / BN;  // (kk*KK2 + tap)*2 + half
+                rw[i] = *reinterpret_cast<const uint4*>(wp + ((size_t)th * CP + r) * 16);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            const int u = i * 256 + tid;
+            if (u < PXU_TOTAL) {
+                const int kk = u / (2 * IN_PIX);
+                const int v = u % (2 * IN_PIX);
+                const int P = v >> 1, h = v & 1;
+                *reinterpret_cast<uint4*>(lds + kk * PIX_SLAB + (h * IN_PIX + P) * 16) = rpx[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int u = i * 256 + tid;
+            if (u < WU_TOTAL) *reinterpret_cast<uint4*>(lds + W_BASE + u * 16) = rw[i];
+        }
+    };
+
+    // ---- fragment addresses -------------------------------------------------------------------
+    int pb[NT];  // byte offset of this lane's pixel (tap 0,0) inside a pixel slab
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int ty = p / TW, tx = p % TW;
+        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
+    }
+    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int nstages = a.cin / (16 * NK);
+    issue(0);
+    commit();
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const bool more = (s + 1 < nstages);
+        if (more) issue(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+#pragma unroll
+            for (int tap = 0; tap < KK2; ++tap) {
+                const int kh = tap / KS, kw = tap % KS;
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    af[m] = *reinterpret_cast<const bf16x8*>(lds + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bfr[n] = *reinterpret_cast<const bf16x8*>(lds + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (more) {
+            __syncthreads();
+            commit();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: affine + leaky (+ residual) -> direct stores -----------------------------------
+    // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
+    // v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
+    const size_t out_plane_px = (size_t)a.hout * a.wout;
+    const int cbase = cg * BN + wm * MT * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int oy = y0 + p / TW, ox = x0 + p % TW;
+        const bool ok = (oy < a.hout) && (ox < a.wout);
+        const size_t pix = (size_t)oy * a.wout + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
+                const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
+                float v[4], w[4];
+                {
+                    const float4 s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
+                    const float4 t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
+                    const float4 s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
+                    const float4 t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
+                    const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
+                    const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x0v = acc[m][n][(2 * qp) * 4 + j] * ss0[j] + tt0[j];
+                        float x1v = acc[m][n][(2 * qp + 1) * 4 + j] * ss1[j] + tt1[j];
+                        if (a.leaky) {
+                            x0v = x0v > 0.f ? x0v : 0.1f * x0v;
+                            x1v = x1v > 0.f ? x1v : 0.1f * x1v;
+                        }
+                        v[j] = x0v;
+                        w[j] = x1v;
+                    }
+                }
+                const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
+                if constexpr (OUT_F32) {
+                    // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
+                    if (ok) {
+                        float* o = reinterpret_cast<float*>(a.out) + (plane * out_plane_px + pix) * 16;
+                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w[0], w[1], w[2], w[3]);
+                    }
+                } else {
+                    const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
+                    if constexpr (HAS_RES) {
+                        // swap in fp32 so the residual is added before the single bf16 rounding
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[j]),
+                                                                      __builtin_bit_cast(unsigned, w[j]), false, false);
+                            v[j] = __builtin_bit_cast(float, r[0]);
+                            w[j] = __builtin_bit_cast(float, r[1]);
+                        }
+                        if (ok) {
+                            const uint4 rr = *reinterpret_cast<const uint4*>(a.residual + ob);
+                            const unsigned rv[4] = {rr.x, rr.y, rr.z, rr.w};
+                            float f[8] = {v[0], v[1], v[2], v[3], w[0], w[1], w[2], w[3]};
+                            unsigned o[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float lo = f[2 * j] + bf2f((uint16_t)(rv[j] & 0xffffu));
+                                const float hi = f[2 * j + 1] + bf2f((uint16_t)(rv[j] >> 16));
+                                o[j] = pack2bf(lo, hi);
+                            }
+                            *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(o[0], o[1], o[2], o[3]);
+                        }
+                    } else {
+                        unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
+                        unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
+                        if (ok) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32>
+static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
+                  const void* residual, void* out, hipStream_t st) {
+    ConvArgs a;
+    a.src = (const uint8_t*)src;
+    a.w = (const uint8_t*)w;
+    a.scale = scale;
+    a.shift = shift;
+    a.residual = (const uint8_t*)residual;
+    a.out = (uint8_t*)out;
+    a.batch = d->batch;
+    a.cin = d->cin;
+    a.cout_pad = d->cout_pad;
+    a.hin = d->hin;
+    a.win = d->win;
+    a.hout = d->hout;
+    a.wout = d->wout;
+    a.tiles_x = (d->wout + TW - 1) / TW;
+    a.tiles_y = (d->hout + TH - 1) / TH;
+    a.n_cgroups = d->cout_pad / BN;
+    a.leaky = d->leaky;
+    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        set_error("conv grid out of range (%lld)", nblk);
+        return AY_ERR_ARG;
+    }
+    dim3 grid((unsigned)nblk), block(256);
+    if constexpr (OUT_F32) {
+        hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false>), grid, block, 0, st, a);
+    } else {
+        if (residual)
+            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
+    }
+    AY_CHECK_LAUNCH("conv_bf16_kernel");
+    return AY_OK;
+}
+
+}  // namespace ay
+
+extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                                const float* shift, const void* residual, void* out, ay_stream_t stream) {
+    using namespace ay;
+    AY_CHECK_ARG(d && src && w_packed && scale && shift && out, "ay_conv_fwd_bf16: null argument");
+    AY_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "ay_conv_fwd_bf16: ksize %d unsupported", d->ksize);
+    AY_CHECK_ARG(d->stride == 1 || (d->stride == 2 && d->ksize == 3), "ay_conv_fwd_bf16: stride %d unsupported", d->stride);
+    AY_CHECK_ARG(d->cin % 16 == 0 && d->cout_pad % 32 == 0 && d->cout_pad >= d->cout, "ay_conv_fwd_bf16: channels %d->%d(%d)",
+                 d->cin, d->cout, d->cout_pad);
+    const int pad = (d->ksize - 1) / 2;
+    AY_CHECK_ARG(d->hout == (d->hin + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (d->win + 2 * pad - d->ksize) / d->stride + 1,
+                 "ay_conv_fwd_bf16: output size mismatch");
+    AY_CHECK_ARG(!(d->out_f32 && residual), "ay_conv_fwd_bf16: f32 output has no residual form");
+    hipStream_t st = S(stream);
+    const int cp = d->cout_pad;
+    if (d->ksize == 3 && d->stride == 1) {
+        AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
+        if (cp % 128 == 0) return launch<3, 1, 128, 2, 2, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 1, 64, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<3, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+    }
+    if (d->ksize == 3 && d->stride == 2) {
+        AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
+        if (cp % 128 == 0) return launch<3, 2, 128, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 2, 64, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<3, 2, 32, 1, 4, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+    }
+    // 1x1
+    if (d->cin % 64 == 0) {
+        if (d->out_f32) {
+            if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
+            return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
+        }
+        if (cp % 128 == 0) return launch<1, 1, 128, 2, 2, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<1, 1, 32, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
+    }
+    if (d->out_f32) return launch<1, 1, 32, 1, 4, 8, 32, 1, true>(d, src, w_packed, scale, shift, residual, out, st);
+    return launch<1, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+}

@@ -1,0 +1,272 @@
+// Confidence-weighted merge-NMS of the reference (utils/utils.py:235-273) on gfx950.
+//
+//   nms_filter_kernel   whole grid: corners in place (:244), conf >= thr filter (:248), score = conf * max cls
+//                       (:253), appends a 64-bit sort key per candidate: (~score_bits << 32) | row, so an
+//                       ascending sort = score descending, ties -> lower original row first.
+//   nms_merge_kernel    one workgroup per image: bitonic sort of the keys (LDS when they fit), gather of the
+//                       candidates in sorted order, then the greedy class-aware scan (:260-269) by one
+//                       64-lane wavefront: the "alive" set is a bitmask of 64-bit words, each lane tests one
+//                       candidate of a word against the current head, __ballot() gives the suppression mask
+//                       of the word, the members' conf-weighted corner sums are wave-reduced for the merge.
+//
+// IoU uses the reference's +1-pixel rule and operation order (fp32, no contraction) so `> nms_thres`
+// decisions are bit-identical; only the merged corners (a sum whose order the reference does not fix)
+// differ in the last bits.
+#include "ay_common.h"
+
+namespace ay {
+
+__device__ __forceinline__ float iou_p1(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2,
+                                        float by2) {
+    const float ix1 = fmaxf(ax1, bx1), iy1 = fmaxf(ay1, by1);
+    const float ix2 = fminf(ax2, bx2), iy2 = fminf(ay2, by2);
+    const float inter = fmaxf(ix2 - ix1 + 1.0f, 0.0f) * fmaxf(iy2 - iy1 + 1.0f, 0.0f);
+    const float a1 = (ax2 - ax1 + 1.0f) * (ay2 - ay1 + 1.0f);
+    const float a2 = (bx2 - bx1 + 1.0f) * (by2 - by1 + 1.0f);
+    return inter / (a1 + a2 - inter + 1e-16f);
+}
+
+static inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// workspace layout per image (cap = next_pow2(n_rows)):
+//   keys  u64[cap] | cand f32[8][cap] (x1,y1,x2,y2,conf,cls_conf,cls_pred,row-as-int)
+struct NmsWs {
+    unsigned long long* keys;
+    float* cand;
+    int cap;
+};
+
+__global__ void nms_filter_kernel(float* __restrict__ pred, int N, int C, float conf_thres, unsigned long long* keys, int cap,
+                                  int* cand_count) {
+    const int b = blockIdx.y;
+    const int K = 5 + C;
+    float* pb = pred + (size_t)b * N * K;
+    unsigned long long* kb = keys + (size_t)b * cap;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
+        float* p = pb + (size_t)r * K;
+        const float cx = p[0], cy = p[1], hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+        p[0] = cx - hw;
+        p[1] = cy - hh;
+        p[2] = cx + hw;
+        p[3] = cy + hh;
+        const float conf = p[4];
+        if (conf >= conf_thres) {
+            float mc = p[5];
+            for (int k = 1; k < C; ++k) mc = fmaxf(mc, p[5 + k]);
+            const float score = conf * mc;
+            const unsigned sb = __builtin_bit_cast(unsigned, score);
+            const int pos = atomicAdd(&cand_count[b], 1);
+            kb[pos] = ((unsigned long long)(~sb) << 32) | (unsigned)r;
+        }
+    }
+}
+
+template <typename P>
+__device__ void bitonic_sort(P d, int n, int tid, int nthreads) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = d[i], y = d[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((x > y) == up) {
+                        d[i] = y;
+                        d[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int NMS_LDS_KEYS = 4096;  // 32 KiB of keys sorted in LDS; larger candidate sets sort in the workspace
+
+__global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict__ pred, int N, int C, float nms_thres,
+                                                        unsigned long long* keys, float* cand, int cap,
+                                                        const int* __restrict__ cand_count, int max_det,
+                                                        float* __restrict__ out_rows, int* __restrict__ keep_idx,
+                                                        int* __restrict__ count) {
+    __shared__ unsigned long long skeys[NMS_LDS_KEYS];
+    __shared__ unsigned long long alive_s[1024];  // up to 65536 candidates
+    volatile unsigned long long* alive = alive_s;  // lane 0 publishes, all lanes re-read: never cache
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int K = 5 + C;
+    int n = cand_count[b];
+    if (n > N) n = N;
+    if (n == 0) {
+        if (tid == 0) count[b] = 0;
+        return;
+    }
+    unsigned long long* kb = keys + (size_t)b * cap;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    // ---- sort ------------------------------------------------------------------------------------
+    const bool in_lds = np2 <= NMS_LDS_KEYS;
+    if (in_lds) {
+        for (int i = tid; i < np2; i += 256) skeys[i] = i < n ? kb[i] : ~0ull;
+        __syncthreads();
+        bitonic_sort(skeys, np2, tid, 256);
+    } else {
+        for (int i = n + tid; i < np2; i += 256) kb[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort(kb, np2, tid, 256);
+    }
+    // ---- gather candidates in sorted order (:255-258) -------------------------------------------
+    float* cb = cand + (size_t)b * 8 * cap;
+    const float* pb = pred + (size_t)b * N * K;
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long key = in_lds ? skeys[i] : kb[i];
+        const int r = (int)(unsigned)(key & 0xffffffffu);
+        const float* p = pb + (size_t)r * K;
+        float mc = p[5];
+        int arg = 0;
+        for (int k = 1; k < C; ++k) {
+            const float v = p[5 + k];
+            if (v > mc) {  // first maximum wins, like torch.max
+                mc = v;
+                arg = k;
+            }
+        }
+        cb[0 * cap + i] = p[0];
+        cb[1 * cap + i] = p[1];
+        cb[2 * cap + i] = p[2];
+        cb[3 * cap + i] = p[3];
+        cb[4 * cap + i] = p[4];
+        cb[5 * cap + i] = mc;
+        cb[6 * cap + i] = (float)arg;
+        reinterpret_cast<int*>(cb)[7 * cap + i] = r;
+    }
+    const int nwords = (n + 63) >> 6;
+    for (int i = tid; i < nwords; i += 256) {
+        const int rem = n - i * 64;
+        alive[i] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- greedy scan by one wavefront ---------------------------------------------------------------
+    const int lane = tid;
+    int kept = 0;
+    int cw = 0;
+    while (true) {
+        unsigned long long aw = 0;
+        while (cw < nwords && (aw = alive[cw]) == 0ull) ++cw;  // wave-uniform
+        if (cw >= nwords) break;
+        const int head = cw * 64 + __builtin_ctzll(aw);
+        const float hx1 = cb[0 * cap + head], hy1 = cb[1 * cap + head], hx2 = cb[2 * cap + head], hy2 = cb[3 * cap + head];
+        const float hcls = cb[6 * cap + head];
+        float sw = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int w = cw; w < nwords; ++w) {
+            const unsigned long long a = alive[w];
+            if (a == 0ull) continue;
+            const int j = w * 64 + lane;
+            bool member = (j == head);  // the head always leaves the set (also when its IoU is NaN)
+            if ((a >> lane) & 1ull) {
+                const float x1 = cb[0 * cap + j], y1 = cb[1 * cap + j], x2 = cb[2 * cap + j], y2 = cb[3 * cap + j];
+                const float iou = iou_p1(hx1, hy1, hx2, hy2, x1, y1, x2, y2);
+                member = member || ((iou > nms_thres) && (cb[6 * cap + j] == hcls));
+                if (member) {
+                    const float wgt = cb[4 * cap + j];
+                    sw += wgt;
+                    s0 += wgt * x1;
+                    s1 += wgt * y1;
+                    s2 += wgt * x2;
+                    s3 += wgt * y2;
+                }
+            }
+            const unsigned long long m = __ballot(member);
+            if (lane == 0) alive[w] = a & ~m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sw += __shfl_xor(sw, off);
+            s0 += __shfl_xor(s0, off);
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+            s3 += __shfl_xor(s3, off);
+        }
+        if (lane == 0 && kept < max_det) {
+            float* o = out_rows + ((size_t)b * max_det + kept) * 7;
+            o[0] = s0 / sw;
+            o[1] = s1 / sw;
+            o[2] = s2 / sw;
+            o[3] = s3 / sw;
+            o[4] = cb[4 * cap + head];
+            o[5] = cb[5 * cap + head];
+            o[6] = hcls;
+            keep_idx[(size_t)b * max_det + kept] = reinterpret_cast<const int*>(cb)[7 * cap + head];
+        }
+        ++kept;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) count[b] = kept;  // > max_det means the caller's buffers were too small (rows were dropped)
+}
+
+}  // namespace ay
+
+using namespace ay;
+
+extern "C" size_t ay_nms_workspace_bytes(int batch, int n_rows) {
+    if (batch <= 0 || n_rows <= 0) return 0;
+    const size_t cap = (size_t)next_pow2(n_rows);
+    return (size_t)batch * cap * (8 + 8 * 4);
+}
+
+static int nms_args_ok(int batch, int n_rows, int num_classes, size_t workspace_bytes, const char* who) {
+    if (!(batch > 0 && n_rows > 0 && n_rows <= 65536 && num_classes >= 1)) {
+        set_error("%s: bad shape (1 <= rows <= 65536)", who);
+        return AY_ERR_ARG;
+    }
+    if (workspace_bytes < ay_nms_workspace_bytes(batch, n_rows)) {
+        set_error("%s: workspace %zu < %zu", who, workspace_bytes, ay_nms_workspace_bytes(batch, n_rows));
+        return AY_ERR_WORKSPACE;
+    }
+    return AY_OK;
+}
+
+extern "C" int ay_nms_filter(float* pred, int batch, int n_rows, int num_classes, float conf_thres, int32_t* cand_count,
+                             void* workspace, size_t workspace_bytes, ay_stream_t stream) {
+    AY_CHECK_ARG(pred && cand_count && workspace, "ay_nms_filter: null");
+    if (int rc = nms_args_ok(batch, n_rows, num_classes, workspace_bytes, "ay_nms_filter")) return rc;
+    hipStream_t st = S(stream);
+    const int cap = next_pow2(n_rows);
+    if (hipMemsetAsync(cand_count, 0, sizeof(int) * batch, st) != hipSuccess) {
+        set_error("ay_nms_filter: memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    int gx = (n_rows + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(nms_filter_kernel, dim3(gx, batch), dim3(256), 0, st, pred, n_rows, num_classes, conf_thres,
+                       (unsigned long long*)workspace, cap, cand_count);
+    AY_CHECK_LAUNCH("nms_filter_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_nms_sort_merge(const float* pred, int batch, int n_rows, int num_classes, float nms_thres, int max_det,
+                                 float* out_rows, int32_t* keep_idx, int32_t* count, const int32_t* cand_count, void* workspace,
+                                 size_t workspace_bytes, ay_stream_t stream) {
+    AY_CHECK_ARG(pred && out_rows && keep_idx && count && cand_count && workspace && max_det > 0, "ay_nms_sort_merge: null");
+    if (int rc = nms_args_ok(batch, n_rows, num_classes, workspace_bytes, "ay_nms_sort_merge")) return rc;
+    const int cap = next_pow2(n_rows);
+    unsigned long long* keys = (unsigned long long*)workspace;
+    float* cand = (float*)((char*)workspace + (size_t)batch * cap * 8);
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(batch), dim3(256), 0, S(stream), pred, n_rows, num_classes, nms_thres, keys, cand, cap,
+                       cand_count, max_det, out_rows, keep_idx, count);
+    AY_CHECK_LAUNCH("nms_merge_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_nms_merge(float* pred, int batch, int n_rows, int num_classes, float conf_thres, float nms_thres, int max_det,
+                            float* out_rows, int32_t* keep_idx, int32_t* count, int32_t* cand_count, void* workspace,
+                            size_t workspace_bytes, ay_stream_t stream) {
+    if (int rc = ay_nms_filter(pred, batch, n_rows, num_classes, conf_thres, cand_count, workspace, workspace_bytes, stream)) return rc;
+    return ay_nms_sort_merge(pred, batch, n_rows, num_classes, nms_thres, max_det, out_rows, keep_idx, count, cand_count, workspace,
+                             workspace_bytes, stream);
+}

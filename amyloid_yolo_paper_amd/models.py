@@ -1,0 +1,452 @@
+"""Darknet (YOLOv3) host class for the MI355X path.
+
+Mirrors the reference's ``models.py`` call surface -- ``Darknet(config_path, img_size)``,
+``model(x)`` / ``model(x, targets)``, ``load_darknet_weights`` / ``save_darknet_weights``,
+``state_dict`` key names, ``.yolo_layers[i].metrics`` -- (reference ``models.py:225-336``) while the
+forward itself is a planned sequence of calls into ``libamyloid_yolo_hip.so``:
+
+* ``precision="bf16"`` (default): fp32 stem -> blocked-bf16 MFMA convolutions with fused
+  BN-affine/LeakyReLU/shortcut epilogues, route+upsample gather, fp32 linear heads, fused decode.
+* ``precision="fp32"``: every block through the fp32 nchw kernel (reference layout, reference
+  precision) -- the mode the 1e-4 parity tests run.
+
+The ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects in ``module_list`` are parameter containers only (they give
+the reference's ``state_dict`` schema, optimiser hooks and ``.to(device)``); they are never called.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ConvDesc, check, ptr
+from .parse_config import parse_model_config
+
+
+class Upsample(nn.Module):
+    """nearest x``scale_factor`` placeholder (reference ``models.py:86-96``); executed inside the plan."""
+
+    def __init__(self, scale_factor, mode="nearest"):
+        super().__init__()
+        self.scale_factor, self.mode = scale_factor, mode
+
+
+class EmptyLayer(nn.Module):
+    """route / shortcut placeholder."""
+
+
+class YOLOLayer(nn.Module):
+    """Detection-layer descriptor (anchors, class count, metrics dict); reference ``models.py:98-125``."""
+
+    def __init__(self, anchors, num_classes, img_dim=416):
+        super().__init__()
+        self.anchors = anchors
+        self.num_anchors = len(anchors)
+        self.num_classes = num_classes
+        self.ignore_thres = 0.5
+        self.obj_scale = 1
+        self.noobj_scale = 100
+        self.metrics = {}
+        self.img_dim = img_dim
+        self.grid_size = 0
+
+
+def create_modules(module_defs):
+    """cfg blocks -> (hyperparams, ModuleList) with the reference's module names (``models.py:16-83``)."""
+    hyperparams = module_defs.pop(0)
+    filters_out = [int(hyperparams["channels"])]
+    module_list = nn.ModuleList()
+    for i, d in enumerate(module_defs):
+        seq = nn.Sequential()
+        kind = d["type"]
+        if kind == "convolutional":
+            bn = int(d["batch_normalize"])
+            filters = int(d["filters"])
+            k = int(d["size"])
+            seq.add_module(f"conv_{i}", nn.Conv2d(filters_out[-1], filters, k, int(d["stride"]), (k - 1) // 2, bias=not bn))
+            if bn:
+                seq.add_module(f"batch_norm_{i}", nn.BatchNorm2d(filters, momentum=0.9, eps=1e-5))
+            if d["activation"] == "leaky":
+                seq.add_module(f"leaky_{i}", nn.LeakyReLU(0.1))
+        elif kind == "maxpool":
+            raise NotImplementedError("maxpool (yolov3-tiny) is outside the accelerated path (SURVEY.md §2)")
+        elif kind == "upsample":
+            filters = filters_out[-1]
+            seq.add_module(f"upsample_{i}", Upsample(int(d["stride"])))
+        elif kind == "route":
+            filters = sum(filters_out[1:][int(j)] for j in d["layers"].split(","))
+            seq.add_module(f"route_{i}", EmptyLayer())
+        elif kind == "shortcut":
+            filters = filters_out[1:][int(d["from"])]
+            seq.add_module(f"shortcut_{i}", EmptyLayer())
+        elif kind == "yolo":
+            filters = filters_out[-1]
+            mask = [int(v) for v in d["mask"].split(",")]
+            flat = [int(v) for v in d["anchors"].split(",")]
+            anchors = [(flat[2 * m], flat[2 * m + 1]) for m in mask]
+            seq.add_module(f"yolo_{i}", YOLOLayer(anchors, int(d["classes"]), int(hyperparams["height"])))
+        else:
+            raise ValueError(f"unknown cfg block [{kind}]")
+        module_list.append(seq)
+        filters_out.append(filters)
+    return hyperparams, module_list
+
+
+def _pad_to(v, m):
+    return (v + m - 1) // m * m
+
+
+class Darknet(nn.Module):
+    """YOLOv3 detector; see module docstring."""
+
+    def __init__(self, config_path, img_size=416, precision="bf16"):
+        super().__init__()
+        self.module_defs = parse_model_config(config_path)
+        self.hyperparams, self.module_list = create_modules(self.module_defs)
+        self.yolo_layers = [m[0] for m in self.module_list if isinstance(m[0], YOLOLayer)]
+        self.img_size = img_size
+        self.seen = 0
+        self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        self._graph = self._analyse()
+        self._prep = None       # packed weights / folded BN, keyed by parameter versions
+        self._buffers = {}      # (precision, B, S) -> per-layer device tensors
+        self.keep_layer_outputs = False
+        self.layer_outputs = None
+
+    # ------------------------------------------------------------------ graph analysis
+    def _analyse(self):
+        """Static per-layer info: channels, resolved source indices, fusion decisions."""
+        defs = self.module_defs
+        n = len(defs)
+        ch = []
+        info = []
+        cin = int(self.hyperparams["channels"])
+        scale = []  # log2 downsample factor relative to the input
+        for i, d in enumerate(defs):
+            t = d["type"]
+            e = {"type": t}
+            prev_ch = ch[-1] if ch else cin
+            prev_sc = scale[-1] if scale else 0
+            if t == "convolutional":
+                e.update(cin=prev_ch, cout=int(d["filters"]), k=int(d["size"]), stride=int(d["stride"]),
+                         bn=bool(int(d["batch_normalize"])), leaky=d["activation"] == "leaky", src=i - 1)
+                c, s = e["cout"], prev_sc + (1 if e["stride"] == 2 else 0)
+            elif t == "upsample":
+                assert int(d["stride"]) == 2, "only x2 nearest upsample is supported"
+                e.update(src=i - 1)
+                c, s = prev_ch, prev_sc - 1
+            elif t == "route":
+                srcs = [int(j) for j in d["layers"].split(",")]
+                srcs = [j if j >= 0 else i + j for j in srcs]
+                e.update(srcs=srcs)
+                c, s = sum(ch[j] for j in srcs), scale[srcs[0]]
+                assert all(scale[j] == s for j in srcs)
+            elif t == "shortcut":
+                j = int(d["from"])
+                e.update(a=i - 1, b=j if j >= 0 else i + j)
+                c, s = prev_ch, prev_sc
+            elif t == "yolo":
+                e.update(src=i - 1)
+                c, s = prev_ch, prev_sc
+            ch.append(c)
+            scale.append(s)
+            e.update(channels=c, log2_down=s)
+            info.append(e)
+        # consumers of every layer output
+        users = {i: [] for i in range(n)}
+        for i, e in enumerate(info):
+            for j in ([e["src"]] if "src" in e else []) + e.get("srcs", []) + ([e["a"], e["b"]] if "a" in e else []):
+                if j >= 0:
+                    users[j].append(i)
+        for i, e in enumerate(info):
+            # conv whose only consumer is the next shortcut (as its "-1" operand): fuse the add into the epilogue
+            e["fuse_into_shortcut"] = (e["type"] == "convolutional" and users[i] == [i + 1] and i + 1 < n
+                                       and info[i + 1]["type"] == "shortcut" and info[i + 1]["a"] == i
+                                       and info[i + 1]["b"] != i)
+        self._users = users
+        return info
+
+    # ------------------------------------------------------------------ weights I/O (reference models.py:257-336)
+    def load_darknet_weights(self, weights_path):
+        """Darknet binary: int32[5] header, then per conv block BN(beta,gamma,mean,var)|bias, then W (OIHW)."""
+        with open(weights_path, "rb") as fh:
+            header = np.fromfile(fh, dtype=np.int32, count=5)
+            weights = np.fromfile(fh, dtype=np.float32)
+        self.header_info = header
+        self.seen = header[3]
+        cutoff = 75 if "darknet53.conv.74" in weights_path else None
+        pos = 0
+
+        def take(t):
+            nonlocal pos
+            n = t.numel()
+            t.data.copy_(torch.from_numpy(weights[pos:pos + n]).view_as(t))
+            pos += n
+
+        for i, (d, m) in enumerate(zip(self.module_defs, self.module_list)):
+            if i == cutoff:
+                break
+            if d["type"] != "convolutional":
+                continue
+            conv = m[0]
+            if int(d["batch_normalize"]):
+                bn = m[1]
+                for t in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                    take(t)
+            else:
+                take(conv.bias)
+            take(conv.weight)
+        self._prep = None
+
+    def save_darknet_weights(self, path, cutoff=-1):
+        with open(path, "wb") as fh:
+            self.header_info[3] = self.seen
+            self.header_info.tofile(fh)
+            for d, m in zip(self.module_defs[:cutoff], self.module_list[:cutoff]):
+                if d["type"] != "convolutional":
+                    continue
+                conv = m[0]
+                if int(d["batch_normalize"]):
+                    bn = m[1]
+                    for t in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                        t.data.cpu().numpy().tofile(fh)
+                else:
+                    conv.bias.data.cpu().numpy().tofile(fh)
+                conv.weight.data.cpu().numpy().tofile(fh)
+
+    # ------------------------------------------------------------------ parameter preparation
+    def _param_signature(self):
+        sig = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t.data_ptr(), t._version))
+        return hash(tuple(sig))
+
+    def _prepare(self, device):
+        sig = (self._param_signature(), self.precision, str(device))
+        if self._prep is not None and self._prep["sig"] == sig:
+            return self._prep
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        prep = {"sig": sig, "layers": {}}
+        for i, e in enumerate(self._graph):
+            if e["type"] != "convolutional":
+                continue
+            m = self.module_list[i]
+            conv = m[0]
+            w = conv.weight.detach().to(device=device, dtype=torch.float32).contiguous()
+            cout = e["cout"]
+            first = (i == 0 and e["cin"] == 3 and e["k"] == 3 and e["stride"] == 1 and cout == 32)
+            cpad = cout if self.precision == "fp32" else _pad_to(cout, 32)
+            scale = torch.empty(cpad, device=device, dtype=torch.float32)
+            shift = torch.empty(cpad, device=device, dtype=torch.float32)
+            if e["bn"]:
+                bn = m[1]
+                g, b_, mu, var = (t.detach().to(device=device, dtype=torch.float32).contiguous()
+                                  for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+                check(L.ay_fold_bn(ptr(g), ptr(b_), ptr(mu), ptr(var), None, C.c_float(bn.eps), ptr(scale), ptr(shift), cout, cpad, st),
+                      "ay_fold_bn")
+            else:
+                bias = conv.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+                check(L.ay_fold_bn(None, None, None, None, ptr(bias), C.c_float(0.0), ptr(scale), ptr(shift), cout, cpad, st),
+                      "ay_fold_bn")
+            entry = dict(scale=scale, shift=shift, cpad=cpad, w=w, stem=first and self.precision == "bf16")
+            if self.precision == "bf16" and not entry["stem"]:
+                assert e["cin"] % 16 == 0, f"layer {i}: cin {e['cin']} is not a multiple of 16"
+                nbytes = L.ay_packed_weight_bytes(cpad, e["cin"], e["k"])
+                packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
+                check(L.ay_pack_conv_weights_bf16(ptr(w), ptr(packed), cout, cpad, e["cin"], e["k"], st), "ay_pack_conv_weights_bf16")
+                entry["packed"] = packed
+            prep["layers"][i] = entry
+        torch.cuda.current_stream().synchronize()  # temporaries (g,b_,mu,var,bias) die here
+        self._prep = prep
+        return prep
+
+    # ------------------------------------------------------------------ forward
+    def num_boxes(self, S):
+        return sum(y.num_anchors * (S >> e["log2_down"]) ** 2 for y, e in
+                   zip(self.yolo_layers, [g for g in self._graph if g["type"] == "yolo"]))
+
+    def forward(self, x, targets=None):
+        """Reference semantics (``models.py:237-255``): returns the CPU tensor ``[B, N, 5+C]``; the device copy is
+        kept as ``out._ay_device`` so ``non_max_suppression`` does not upload it again."""
+        if targets is not None or self.training:
+            raise NotImplementedError(
+                "training forward/backward on the HIP path is not built yet (SURVEY.md §8 row 'train step'); "
+                "call model.eval() for inference")
+        dev_out = self.forward_device(x)
+        out = dev_out.detach().cpu()
+        self._gen = getattr(self, "_gen", 0) + 1
+        dev_out._ay_gen = out._ay_gen = self._gen  # lets NMS tell that the device buffer still holds THIS output
+        out._ay_device = dev_out
+        return out
+
+    @torch.no_grad()
+    def forward_device(self, x):
+        """x [B,3,S,S] float32 (any device) -> device tensor [B, N, 5+C] (valid until the next forward)."""
+        if not torch.cuda.is_available():
+            raise _lib.AyError("no HIP device: the amyloid-yolo hot path has no CPU fallback")
+        L = _lib.lib()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        B, Cin, S, S2 = x.shape
+        assert S == S2 and S % 32 == 0, "square inputs with side divisible by 32 (reference models.py:238, datasets.py:78)"
+        assert Cin == int(self.hyperparams["channels"])
+        prep = self._prepare(dev)
+        st = _lib.stream_ptr()
+        bf16 = self.precision == "bf16"
+        key = (self.precision, B, S)
+        bufs = self._buffers.setdefault(key, {})
+        C_ = self.yolo_layers[0].num_classes
+        N = self.num_boxes(S)
+        if "out" not in bufs:
+            bufs["out"] = torch.empty(B, N, 5 + C_, device=dev, dtype=torch.float32)
+        out = bufs["out"]
+
+        def size_of(i):
+            return S >> self._graph[i]["log2_down"] if i >= 0 else S
+
+        def buf(i, f32=False, ch=None):
+            """persistent output buffer of layer i"""
+            if i not in bufs:
+                e = self._graph[i]
+                h = size_of(i)
+                c = e["channels"] if ch is None else ch
+                if not bf16:
+                    bufs[i] = torch.empty(B, c, h, h, device=dev, dtype=torch.float32)
+                elif f32:
+                    bufs[i] = torch.empty(B, _pad_to(c, 32) // 16, h, h, 16, device=dev, dtype=torch.float32)
+                else:
+                    bufs[i] = torch.empty(B, _pad_to(c, 16) // 16, h, h, 16, device=dev, dtype=torch.bfloat16)
+            return bufs[i]
+
+        # values: ("t", tensor) materialised, ("up", layer) lazily upsampled view of another layer
+        val = {}
+
+        def resolve(i):
+            """materialised tensor of layer i's output"""
+            v = val[i]
+            if v[0] == "t":
+                return v[1]
+            src = resolve(v[1])  # lazy upsample -> materialise
+            c = self._graph[i]["channels"]
+            o = buf(i)
+            h = size_of(i)
+            if bf16:
+                check(L.ay_concat_upsample_bf16(ptr(src), c, 1, None, 0, ptr(o), B, h, h, st), "ay_concat_upsample_bf16")
+            else:
+                o.copy_(src.repeat_interleave(2, 2).repeat_interleave(2, 3))
+            val[i] = ("t", o)
+            return o
+
+        row = 0
+        prof = getattr(self, "profile_layers", None)  # bench.py: bracket these conv launches with HIP events
+        for i, e in enumerate(self._graph):
+            t = e["type"]
+            if t == "convolutional":
+                p = prep["layers"][i]
+                hin, hout = size_of(e["src"]), size_of(i)
+                fuse = e["fuse_into_shortcut"]
+                res = resolve(self._graph[i + 1]["b"]) if fuse else None
+                is_head = not e["bn"] and not e["leaky"]
+                d = ConvDesc(B, e["cin"], e["cout"], hin, hin, hout, hout, e["k"], e["stride"], int(e["leaky"]),
+                             int(bf16 and is_head), p["cpad"])
+                tgt = i + 1 if fuse else i
+                if bf16:
+                    if p["stem"]:
+                        o = buf(tgt)
+                        check(L.ay_stem_conv_fwd(ptr(x), ptr(p["w"]), ptr(p["scale"]), ptr(p["shift"]), ptr(o), B, S, S,
+                                                 int(e["leaky"]), st), "ay_stem_conv_fwd")
+                    else:
+                        src = x if e["src"] < 0 else resolve(e["src"])
+                        if e["src"] < 0:
+                            raise NotImplementedError("bf16 path expects the 3->32 3x3 stem as layer 0")
+                        o = buf(tgt, f32=is_head)
+                        timed = prof is not None and i in prof
+                        if timed:
+                            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            ev0.record()
+                        check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]),
+                                                 ptr(res), ptr(o), st), "ay_conv_fwd_bf16")
+                        if timed:
+                            ev1.record()
+                            self.profile_events.append((i, ev0, ev1))
+                else:
+                    # route/upsample folded into the loader when the source is a lazy value
+                    s1, c1, up1, s2 = self._f32_sources(e["src"], x, val, resolve)
+                    o = buf(tgt)
+                    check(L.ay_conv_fwd_f32(C.byref(d), ptr(s1), c1, up1, ptr(s2), ptr(p["w"]), ptr(p["scale"]), ptr(p["shift"]),
+                                            ptr(res), ptr(o), st), "ay_conv_fwd_f32")
+                val[i] = ("t", o)
+                if fuse:
+                    val[i] = ("fused", None)
+                    val[i + 1] = ("t", o)
+            elif t == "shortcut":
+                if i in val:
+                    continue  # produced by the fused epilogue of the previous conv
+                raise NotImplementedError(f"layer {i}: unfused shortcut (a source other than the preceding conv)")
+            elif t == "upsample":
+                val[i] = ("up", e["src"])
+            elif t == "route":
+                srcs = e["srcs"]
+                if len(srcs) == 1:
+                    val[i] = val[srcs[0]] if val[srcs[0]][0] != "up" else ("t", resolve(srcs[0]))
+                elif len(srcs) == 2:
+                    if bf16:
+                        a, b_ = srcs
+                        up = val[a][0] == "up"
+                        s1 = resolve(val[a][1]) if up else resolve(a)
+                        s2 = resolve(b_)
+                        o = buf(i)
+                        h = size_of(i)
+                        check(L.ay_concat_upsample_bf16(ptr(s1), self._graph[a]["channels"], int(up), ptr(s2),
+                                                        self._graph[b_]["channels"], ptr(o), B, h, h, st), "ay_concat_upsample_bf16")
+                        val[i] = ("t", o)
+                    else:
+                        val[i] = ("cat", srcs)  # consumed by the next conv's loader
+                else:
+                    raise NotImplementedError("route with more than two sources")
+            elif t == "yolo":
+                y = self.module_list[i][0]
+                head = resolve(e["src"])
+                G = size_of(i)
+                anchors = (C.c_float * (2 * y.num_anchors))(*[float(v) for a in y.anchors for v in a])
+                check(L.ay_yolo_decode(ptr(head), 1 if bf16 else 0, ptr(out), B, y.num_anchors, y.num_classes, G, S, anchors, N,
+                                       row, st), "ay_yolo_decode")
+                y.grid_size, y.img_dim = G, S
+                row += y.num_anchors * G * G
+                val[i] = ("t", head)
+        if self.keep_layer_outputs:
+            self.layer_outputs = {i: v[1] for i, v in val.items() if v[0] == "t"}
+        return out
+
+    def _f32_sources(self, src, x, val, resolve):
+        """(src1, cin1, up1, src2) for the fp32 kernel, folding route/upsample chains."""
+        if src < 0:
+            return x, x.shape[1], 0, None
+        v = val[src]
+        if v[0] == "cat":
+            a, b_ = v[1]
+            up = val[a][0] == "up"
+            s1 = resolve(val[a][1]) if up else resolve(a)
+            return s1, self._graph[a]["channels"], int(up), resolve(b_)
+        if v[0] == "up":
+            s1 = resolve(v[1])
+            return s1, self._graph[src]["channels"], 1, None
+        t = resolve(src)
+        return t, self._graph[src]["channels"], 0, None
+
+    def layer_output_nchw(self, i):
+        """fp32 NCHW copy of a kept layer output (tests); needs keep_layer_outputs=True before forward."""
+        L = _lib.lib()
+        t = self.layer_outputs[i]
+        if t.dtype == torch.float32 and t.dim() == 4:
+            return t.clone()
+        B, P, H, W, _ = t.shape
+        c = self._graph[i]["channels"]
+        o = torch.empty(B, c, H, W, device=t.device, dtype=torch.float32)
+        fn = L.ay_blocked_bf16_to_nchw_f32 if t.dtype == torch.bfloat16 else L.ay_blocked_f32_to_nchw_f32
+        check(fn(ptr(t), ptr(o), B, c, H, W, _lib.stream_ptr()), "blocked_to_nchw")
+        return o

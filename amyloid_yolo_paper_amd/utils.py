@@ -1,0 +1,173 @@
+"""Box math and merge-NMS with the reference's signatures (reference ``utils/utils.py``), executed by
+the HIP library.  Tensors may live on the host or the device; results come back on the input's device,
+as they would from the reference.  Nothing here computes box math on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def to_cpu(tensor):
+    return tensor.detach().cpu()
+
+
+def load_classes(path):
+    """class names, one per line (reference ``utils/utils.py:18-24``: the last line is dropped)."""
+    with open(path, "r") as fh:
+        return fh.read().split("\n")[:-1]
+
+
+def weights_init_normal(m):
+    """reference ``utils/utils.py:27-33``"""
+    name = m.__class__.__name__
+    if name.find("Conv") != -1:
+        torch.nn.init.normal_(m.weight.data, 0.0, 0.02)
+    elif name.find("BatchNorm2d") != -1:
+        torch.nn.init.normal_(m.weight.data, 1.0, 0.02)
+        torch.nn.init.constant_(m.bias.data, 0.0)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.AyError("no HIP device: the amyloid-yolo box kernels have no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(t):
+    return t.detach().to(device=_dev(), dtype=torch.float32).contiguous()
+
+
+def rescale_boxes(boxes, current_dim, original_shape):
+    """undo pad-to-square + resize, in place (reference ``utils/utils.py:36-50``); host-side scalar bookkeeping
+    on an [n,7] detection tensor (not on the accelerated path)."""
+    orig_h, orig_w = original_shape
+    pad_x = max(orig_h - orig_w, 0) * (current_dim / max(original_shape))
+    pad_y = max(orig_w - orig_h, 0) * (current_dim / max(original_shape))
+    unpad_h = current_dim - pad_y
+    unpad_w = current_dim - pad_x
+    boxes[:, 0] = ((boxes[:, 0] - pad_x // 2) / unpad_w) * orig_w
+    boxes[:, 1] = ((boxes[:, 1] - pad_y // 2) / unpad_h) * orig_h
+    boxes[:, 2] = ((boxes[:, 2] - pad_x // 2) / unpad_w) * orig_w
+    boxes[:, 3] = ((boxes[:, 3] - pad_y // 2) / unpad_h) * orig_h
+    return boxes
+
+
+def xywh2xyxy(x):
+    """(cx,cy,w,h) -> corners, new tensor (reference ``utils/utils.py:53-59``)."""
+    shape = x.shape
+    d = _to_dev(x).reshape(-1, shape[-1]).clone()
+    check(_lib.lib().ay_xywh2xyxy(ptr(d), d.shape[0], d.shape[1], _lib.stream_ptr()), "ay_xywh2xyxy")
+    return d.reshape(shape).to(x.device)
+
+
+def bbox_iou(box1, box2, x1y1x2y2=True, giou=False):
+    """+1-pixel IoU of the reference (``utils/utils.py:202-232``); [1|n,4] x [n,4] -> [n].
+    ``giou=True`` is the new GIoU variant (no reference counterpart)."""
+    b1, b2 = _to_dev(box1).reshape(-1, 4), _to_dev(box2).reshape(-1, 4)
+    n1, n2 = b1.shape[0], b2.shape[0]
+    if n2 == 1 and n1 > 1:  # broadcast the other way round (IoU is symmetric)
+        b1, b2, n1, n2 = b2, b1, n2, n1
+    out = torch.empty(n2, device=b1.device, dtype=torch.float32)
+    check(_lib.lib().ay_box_iou(ptr(b1), n1, ptr(b2), n2, int(bool(x1y1x2y2)), int(bool(giou)), ptr(out), _lib.stream_ptr()),
+          "ay_box_iou")
+    return out.to(box1.device)
+
+
+def bbox_iou_pairwise(box1, box2, giou=False):
+    """all-pairs IoU/GIoU of corner boxes: [n1,4] x [n2,4] -> [n1,n2]."""
+    b1, b2 = _to_dev(box1).reshape(-1, 4), _to_dev(box2).reshape(-1, 4)
+    out = torch.empty(b1.shape[0], b2.shape[0], device=b1.device, dtype=torch.float32)
+    check(_lib.lib().ay_box_iou_pairwise(ptr(b1), b1.shape[0], ptr(b2), b2.shape[0], int(bool(giou)), ptr(out), _lib.stream_ptr()),
+          "ay_box_iou_pairwise")
+    return out.to(box1.device)
+
+
+def bbox_wh_iou(wh1, wh2):
+    """anchor-vs-target width/height IoU (reference ``utils/utils.py:193-199``): a 3-op elementwise torch
+    expression evaluated on whatever device the operands live on."""
+    wh2 = wh2.t()
+    w1, h1 = wh1[0], wh1[1]
+    w2, h2 = wh2[0], wh2[1]
+    inter = torch.min(w1, w2) * torch.min(h1, h2)
+    return inter / ((w1 * h1 + 1e-16) + w2 * h2 - inter)
+
+
+class NmsResult(list):
+    """list of ``Tensor[n,7] | None`` (the reference's return value) that also carries, per image, the original
+    row index of every emitted cluster head (``keep_idx``) and the candidate count after the conf filter."""
+    keep_idx = None
+    cand_count = None
+
+
+_ws_cache = {}
+
+
+def nms_workspace(B, N, dev):
+    nbytes = _lib.lib().ay_nms_workspace_bytes(B, N)
+    key = str(dev)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), device=dev, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def nms_device(pred_dev, conf_thres, nms_thres, max_det):
+    """Raw fused device call (no host sync): pred_dev [B,N,5+C] float32 CUDA tensor, corners IN PLACE.
+    Returns (rows [B,max_det,7], keep [B,max_det] i32, count [B] i32, cand_count [B] i32) device tensors;
+    ``count[b] > max_det`` means image b had more cluster heads than the buffers hold."""
+    L = _lib.lib()
+    B, N, K = pred_dev.shape
+    dev = pred_dev.device
+    rows = torch.empty(B, max_det, 7, device=dev, dtype=torch.float32)
+    keep = torch.empty(B, max_det, device=dev, dtype=torch.int32)
+    count = torch.empty(B, device=dev, dtype=torch.int32)
+    cand = torch.empty(B, device=dev, dtype=torch.int32)
+    ws = nms_workspace(B, N, dev)
+    check(L.ay_nms_merge(ptr(pred_dev), B, N, K - 5, C.c_float(conf_thres), C.c_float(nms_thres), max_det, ptr(rows), ptr(keep),
+                         ptr(count), ptr(cand), ptr(ws), ws.numel(), _lib.stream_ptr()), "ay_nms_merge")
+    return rows, keep, count, cand
+
+
+def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.4):
+    """Reference ``utils/utils.py:235-273``: conf filter, score sort, greedy class-aware suppression with
+    confidence-weighted merge.  ``prediction[..., :4]`` becomes corners IN PLACE, as in the reference.
+    Returns ``NmsResult`` (a list of ``[n,7]`` tensors or ``None``) on ``prediction``'s device."""
+    L = _lib.lib()
+    src_dev = prediction.device
+    cached = getattr(prediction, "_ay_device", None)
+    if prediction.is_cuda and prediction.dtype == torch.float32 and prediction.is_contiguous():
+        pred_dev = prediction
+    elif ((not prediction.is_cuda) and cached is not None and cached.shape == prediction.shape
+          and getattr(cached, "_ay_gen", None) == getattr(prediction, "_ay_gen", -1)):
+        pred_dev = cached  # the forward's own device copy of this tensor (models.Darknet.forward)
+    else:
+        pred_dev = _to_dev(prediction)
+    B, N, K = pred_dev.shape
+    dev = pred_dev.device
+    st = _lib.stream_ptr()
+    ws = nms_workspace(B, N, dev)
+    cand = torch.empty(B, device=dev, dtype=torch.int32)
+    check(L.ay_nms_filter(ptr(pred_dev), B, N, K - 5, C.c_float(conf_thres), ptr(cand), ptr(ws), ws.numel(), st), "ay_nms_filter")
+    cand_h = cand.cpu().numpy()  # one small sync: sizes the output exactly (heads <= candidates)
+    max_det = max(int(cand_h.max(initial=0)), 1)
+    rows = torch.empty(B, max_det, 7, device=dev, dtype=torch.float32)
+    keep = torch.empty(B, max_det, device=dev, dtype=torch.int32)
+    count = torch.empty(B, device=dev, dtype=torch.int32)
+    check(L.ay_nms_sort_merge(ptr(pred_dev), B, N, K - 5, C.c_float(nms_thres), max_det, ptr(rows), ptr(keep), ptr(count), ptr(cand),
+                              ptr(ws), ws.numel(), st), "ay_nms_sort_merge")
+    if pred_dev is not prediction:  # the reference mutates the caller's tensor (:244)
+        prediction[..., :4] = pred_dev[..., :4].to(src_dev)
+    cnt = count.cpu().numpy()
+    out = NmsResult()
+    out.keep_idx, out.cand_count = [], cand_h
+    rows_h, keep_h = rows.to(src_dev), keep.cpu().numpy()
+    for b in range(B):
+        n = int(cnt[b])
+        out.append(rows_h[b, :n].clone() if n else None)
+        out.keep_idx.append(keep_h[b, :n].astype(np.int64))
+    return out

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tiles/s of the YOLOv3 hot path (1024x1024 RGB tiles, bf16 MFMA backbone+FPN, decode, merge-NMS)
+on MI355X.  One "step" = one pass over one batch of 64 device-resident synthetic tiles (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel
+(3x3 stride-1 MFMA convolution, BN=128 tile) timed with HIP events on the launch stream inside the timed region and
+`cpu_baseline` = the CPU oracle (torch-CPU fp32 + restated decode/NMS) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--conf_thres", type=float, default=0.5)
+    ap.add_argument("--nms_thres", type=float, default=0.4)
+    ap.add_argument("--max_det", type=int, default=2048)
+    ap.add_argument("--unique_tiles", type=int, default=16, help="distinct synthetic tiles (repeated to fill the batch)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_tiles", type=int, default=4)
+    ap.add_argument("--no_layer_events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--traffic_json", default=os.path.join(REPO, "profiles", "traffic.json"),
+                    help="optional {kernel family: HBM bytes per launch} from a rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def conv_flops(e, B, S):
+    h = S >> e["log2_down"]
+    return 2.0 * B * h * h * e["cout"] * e["cin"] * e["k"] * e["k"]
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from amyloid_yolo_paper_amd import _lib, build as aybuild, cfg_gen, parse_config, synth
+    from amyloid_yolo_paper_amd.models import Darknet
+    from amyloid_yolo_paper_amd.utils import nms_device
+
+    if not os.path.exists(_lib.LIB_PATH):
+        if rank == 0:
+            aybuild.build_library(verbose=False)
+        if world > 1:
+            dist.barrier()
+
+    cfg = cfg_gen.write_cfg(a.classes)
+    defs = parse_config.parse_model_config(cfg)
+    params = synth.synth_params(defs, seed=7)
+    model = Darknet(cfg, img_size=a.size, precision="bf16")
+    sd = model.state_dict()
+    for i, p in params.items():
+        for k, name in (("weight", f"conv_{i}.weight"), ("bias", f"conv_{i}.bias"), ("gamma", f"batch_norm_{i}.weight"),
+                        ("beta", f"batch_norm_{i}.bias"), ("mean", f"batch_norm_{i}.running_mean"), ("var", f"batch_norm_{i}.running_var")):
+            if k in p:
+                sd[f"module_list.{i}.{name}"].copy_(torch.from_numpy(p[k]))
+    model = model.to(dev).eval()
+
+    # synthetic tiles, resident in HBM before the timed region (each rank its own shard of tile indices: weak scaling)
+    nu = min(a.unique_tiles, a.batch)
+    tiles = synth.synth_tiles(nu, a.size, start=rank * nu)
+    x = torch.from_numpy(tiles).to(dev)
+    x = x.repeat((a.batch + nu - 1) // nu, 1, 1, 1)[: a.batch].contiguous()
+
+    # dominant kernel family: 3x3 stride-1 convs whose padded cout is a multiple of 128
+    fam = [i for i, e in enumerate(model._graph) if e["type"] == "convolutional" and e["k"] == 3 and e["stride"] == 1
+           and e["cout"] % 128 == 0 and e["cin"] % 16 == 0]
+    fam_flops = sum(conv_flops(model._graph[i], a.batch, a.size) for i in fam)
+    total_flops = sum(conv_flops(e, a.batch, a.size) for e in model._graph if e["type"] == "convolutional")
+
+    def step():
+        out = model.forward_device(x)
+        return nms_device(out, a.conf_thres, a.nms_thres, a.max_det)
+
+    for _ in range(a.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    model.profile_layers = None if a.no_layer_events else set(fam)
+    model.profile_events = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    events = model.profile_events
+    model.profile_layers = None
+
+    rows, keep, count, cand = res
+    cnt, cnd = count.cpu().numpy(), cand.cpu().numpy()
+    assert cnt.max() <= a.max_det, f"max_det {a.max_det} too small: {cnt.max()} cluster heads"
+    raw_ok = bool(torch.isfinite(rows[0, : max(int(cnt[0]), 1)]).all())
+    assert raw_ok, "non-finite detections"
+
+    tiles_per_s = a.gpus * a.batch * a.steps / elapsed
+    result = {
+        "metric": "tiles/sec (1024x1024 RGB) inference", "value": round(tiles_per_s, 2), "unit": "tiles/s",
+        "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"configs[1]: Darknet-53+FPN YOLOv3, batch={a.batch} synthetic {a.size}x{a.size} tiles/GPU, "
+                               f"C={a.classes}, seeded random weights, decode + merge-NMS on (conf {a.conf_thres}, nms {a.nms_thres})",
+                   "global_batch": a.gpus * a.batch, "tile": a.size, "parallelism": f"replicas x{a.gpus} (tiles sharded by image, no collective)",
+                   "candidates_per_tile": round(float(cnd.mean()), 1), "detections_per_tile": round(float(cnt.mean()), 1),
+                   "model_tflops": round(total_flops * a.steps * a.gpus / elapsed / 1e12, 1)},
+    }
+    if rank == 0:
+        if events:
+            ms = sum(s.elapsed_time(e) for _, s, e in events)
+            launches = len(events)
+            achieved = fam_flops * a.steps / (ms * 1e-3) / 1e12
+            traffic = None
+            try:
+                traffic = json.load(open(a.traffic_json)).get("conv3x3s1_bn128_bytes_per_launch")
+            except Exception:
+                pass
+            result["roofline"] = {
+                "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "kernel": "ay::conv_bf16_kernel<3,1,128,2,2,8,32,1,...> (3x3 s1, 128ch x 256px tile)",
+                "launches_per_step": launches // a.steps, "avg_launch_ms": round(ms / launches, 4),
+                "flops_per_launch": fam_flops / (launches // a.steps), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
+            }
+        if not a.no_cpu_baseline and a.gpus == 1:
+            result["cpu_baseline"] = cpu_baseline(a, cfg, params)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, cfg, params):
+    """The CPU oracle (port of the reference's CPU path) on a bounded sample: `cpu_tiles` tiles, batch 1, all host cores."""
+    import torch
+    from amyloid_yolo_paper_amd import synth
+    from oracle import boxes_oracle as bo
+    from oracle.darknet_oracle import OracleDarknet
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    m = OracleDarknet(cfg)
+    m.set_params(params)
+    tiles = torch.from_numpy(synth.synth_tiles(a.cpu_tiles, a.size, start=0))
+    with torch.no_grad():
+        m.forward(tiles[:1])  # warm
+        t0 = time.perf_counter()
+        t_nms = 0.0
+        for i in range(a.cpu_tiles):
+            out = m.forward(tiles[i:i + 1]).numpy()
+            t2 = time.perf_counter()
+            bo.non_max_suppression(out, a.conf_thres, a.nms_thres)
+            t_nms += time.perf_counter() - t2
+        dt = time.perf_counter() - t0
+    return {"value": round(a.cpu_tiles / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{a.cpu_tiles} of the same synthetic {a.size}x{a.size} tiles, batch 1, fp32 torch-CPU conv stack + restated decode/merge-NMS "
+                      f"({dt:.1f} s total, NMS {t_nms:.2f} s)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/*
+ * amyloid_yolo.h -- C ABI of libamyloid_yolo_hip.so (gfx950 / MI355X).
+ *
+ * The reference (keiserlab/amyloid-yolo-paper) is pure Python/PyTorch and has no FFI for this path
+ * (SURVEY.md §8b); its "operator interface" is the Python call surface of models.py / utils/utils.py.
+ * Each entry point below names the reference code it replaces.  The host-side mirror of that Python
+ * surface lives in amyloid_yolo_paper_amd/{models,utils}.py and binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 on success or a negative AY_ERR_* code; ay_last_error() gives
+ * a thread-local message.  All buffers are caller-allocated DEVICE pointers (the library never
+ * allocates or frees), every call is stream-ordered on `stream` (a hipStream_t passed as void*) and
+ * performs no host synchronisation.  No torch types appear here.
+ *
+ * Activation layouts
+ *   "blocked bf16"  [B][C/16][H][W][16] bfloat16   -- the MFMA path ("c16" planes; C padded to 16)
+ *   "blocked f32"   [B][C/16][H][W][16] float      -- head outputs of the bf16 path
+ *   "nchw f32"      [B][C][H][W] float             -- the reference's layout; fp32 parity path + I/O
+ */
+#ifndef AMYLOID_YOLO_H
+#define AMYLOID_YOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AY_OK 0
+#define AY_ERR_ARG (-1)      /* bad argument / unsupported shape */
+#define AY_ERR_LAUNCH (-2)   /* HIP launch error */
+#define AY_ERR_WORKSPACE (-3)
+
+typedef void* ay_stream_t; /* hipStream_t */
+
+int ay_version(void);
+const char* ay_last_error(void);
+
+/* One convolutional block: conv -> (BN affine | bias) -> LeakyReLU(0.1)? -> (+ residual)?
+ * Replaces models.py:26-45 executed at models.py:242-243, with the following shortcut
+ * (models.py:246-248) fused as `residual`. */
+typedef struct ay_conv_desc {
+    int32_t batch;
+    int32_t cin, cout;         /* logical channels */
+    int32_t hin, win;          /* input spatial size */
+    int32_t hout, wout;        /* output spatial size = floor((hin + 2*pad - k)/stride) + 1, pad=(k-1)/2 */
+    int32_t ksize, stride;     /* 1|3 ; 1|2 */
+    int32_t leaky;             /* 1: LeakyReLU(0.1) after the affine */
+    int32_t out_f32;           /* bf16 path only: 1 = store blocked f32 (linear heads), 0 = blocked bf16 */
+    int32_t cout_pad;          /* channels in scale/shift/packed weights/output planes: multiple of 16 (bf16 path: 32) */
+} ay_conv_desc;
+
+/* ---- bf16 MFMA path -------------------------------------------------------------------------- */
+
+/* OIHW fp32 weights -> packed bf16 [cin/16][k*k][2][cout_pad][8] (zero rows for cout..cout_pad). */
+int ay_pack_conv_weights_bf16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize,
+                              ay_stream_t stream);
+size_t ay_packed_weight_bytes(int cout_pad, int cin, int ksize);
+
+/* BN (eval) -> per-channel scale/shift (models.py:43 semantics, eps passed in); bias-only layers use
+ * gamma=NULL: scale=1, shift=bias.  Pads [n, n_pad) with scale=0, shift=0. */
+int ay_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
+               float eps, float* scale, float* shift, int n, int n_pad, ay_stream_t stream);
+
+/* Stem: nchw f32 image [B,3,H,W] -> blocked bf16 [B][2][H][W][16] (3x3 s1 conv 3->32, fp32 math). */
+int ay_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                     void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream);
+
+/* 3x3 (stride 1|2) and 1x1 convolution, blocked bf16 in, MFMA 32x32x16 bf16, fp32 accumulate,
+ * fused scale/shift + leaky + residual epilogue; `residual` (blocked bf16, output shape) may be NULL. */
+int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                     const float* shift, const void* residual, void* out, ay_stream_t stream);
+
+/* route (models.py:244-245) + nearest x2 upsample (models.py:86-96) as one gather into a blocked bf16
+ * tensor [B][(c1+c2)/16][H][W][16]: src1 [B][c1/16][H>>up1][W>>up1][16], src2 [B][c2/16][H][W][16]|NULL. */
+int ay_concat_upsample_bf16(const void* src1, int c1, int up1, const void* src2, int c2, void* out,
+                            int batch, int h, int w, ay_stream_t stream);
+
+/* layout converters (tests, fp32<->bf16 path bridges) */
+int ay_blocked_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream);
+int ay_blocked_f32_to_nchw_f32(const float* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream);
+int ay_nchw_f32_to_blocked_bf16(const float* src, void* dst, int batch, int c, int h, int w, ay_stream_t stream);
+
+/* ---- fp32 parity path (reference layout) ------------------------------------------------------ */
+
+/* Same block in nchw f32 with OIHW fp32 weights; src2/c-split/up1 implement route+upsample in the
+ * loader: channels [0,cin1) come from src1 read at (y>>up1, x>>up1), [cin1,cin) from src2. */
+int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
+                    const float* w_oihw, const float* scale, const float* shift, const float* residual,
+                    float* out, ay_stream_t stream);
+
+/* ---- YOLO head decode: models.py:127-172 ------------------------------------------------------- */
+/* head: blocked f32 [B][cpad/16][G][G][16], cpad = A*(5+C) rounded up to 32 (layout=1) or nchw f32 [B][A*(5+C)][G][G] (layout=0).
+ * Writes rows [row_offset, row_offset + A*G*G) of out [B][n_total][5+C]:
+ * (sig(tx)+gx)*s, (sig(ty)+gy)*s, exp(tw)*aw, exp(th)*ah, sig(conf), sig(cls...) ; s = img_dim/G. */
+int ay_yolo_decode(const float* head, int layout, float* out, int batch, int num_anchors, int num_classes,
+                   int grid, int img_dim, const float* anchors_wh /* host, A*2, pixels */, int n_total,
+                   int row_offset, ay_stream_t stream);
+
+/* ---- box math: utils/utils.py:53-59,193-232 ---------------------------------------------------- */
+int ay_xywh2xyxy(float* boxes, int64_t n_rows, int row_stride, ay_stream_t stream); /* in place, first 4 cols */
+/* mode 0: IoU with the reference's +1-pixel rule (bbox_iou); mode 1: GIoU (no +1; new, unpinned).
+ * n1 == n2 (elementwise) or n1 == 1 (broadcast); xyxy=0 means (cx,cy,w,h) inputs. out[n2]. */
+int ay_box_iou(const float* box1, int n1, const float* box2, int n2, int xyxy, int mode, float* out,
+               ay_stream_t stream);
+/* all pairs: out[n1][n2] */
+int ay_box_iou_pairwise(const float* box1, int n1, const float* box2, int n2, int mode, float* out,
+                        ay_stream_t stream);
+
+/* ---- merge-NMS: utils/utils.py:235-273 ---------------------------------------------------------- */
+/* pred [B][N][5+C] (cx,cy,w,h,conf,cls..) is converted to corners IN PLACE (reference :244).
+ * Per image: rows with conf >= conf_thres, ordered by conf*max(cls) descending (ties: lower row first),
+ * greedy class-aware suppression (IoU > nms_thres, strict) with confidence-weighted box merge.
+ * out_rows [B][max_det][7] (x1,y1,x2,y2,conf,cls_conf,cls_pred), keep_idx [B][max_det] original row of
+ * each emitted cluster head, count[B] (clamped to max_det), cand_count[B] candidates after the filter. */
+size_t ay_nms_workspace_bytes(int batch, int n_rows);
+/* step 1: corners in place + conf filter + sort keys -> cand_count[B] (lets the caller size max_det exactly) */
+int ay_nms_filter(float* pred, int batch, int n_rows, int num_classes, float conf_thres, int32_t* cand_count,
+                  void* workspace, size_t workspace_bytes, ay_stream_t stream);
+/* step 2: per-image sort + greedy merge scan; pred must already hold corners (step 1) */
+int ay_nms_sort_merge(const float* pred, int batch, int n_rows, int num_classes, float nms_thres, int max_det,
+                      float* out_rows, int32_t* keep_idx, int32_t* count, const int32_t* cand_count,
+                      void* workspace, size_t workspace_bytes, ay_stream_t stream);
+/* both steps back to back, no host sync; count[b] > max_det tells the caller rows were dropped */
+int ay_nms_merge(float* pred, int batch, int n_rows, int num_classes, float conf_thres, float nms_thres,
+                 int max_det, float* out_rows, int32_t* keep_idx, int32_t* count, int32_t* cand_count,
+                 void* workspace, size_t workspace_bytes, ay_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMYLOID_YOLO_H */

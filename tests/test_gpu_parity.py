@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs and against the reference-generated fixtures in tests/golden.
+
+Bars: integer/index results bit-exact; fp32 box/IoU floats within 1e-4 relative (|a-b| <= 1e-4*max(1,|b|));
+bf16 MFMA convolutions within bf16 rounding of an oracle that applies the same rounding points
+(stated per test)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_cases as gc
+from amyloid_yolo_paper_amd import _lib, cfg_gen, parse_config, synth
+from amyloid_yolo_paper_amd import utils as ay
+from amyloid_yolo_paper_amd._lib import ConvDesc, check, ptr
+from amyloid_yolo_paper_amd.models import Darknet
+from oracle import boxes_oracle as bo
+from oracle.darknet_oracle import OracleDarknet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max(initial=0.0) <= tol, (what, float(err.max()), int(err.argmax()))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run on the GPU box"
+    return torch.device("cuda", 0)
+
+
+# ----------------------------------------------------------------------------------------- box math
+def test_box_math_bit_exact(golden_dir, dev):
+    z = load(golden_dir, "kat")
+    b1, b2 = gc.iou_inputs()
+    t1, t2 = torch.from_numpy(b1), torch.from_numpy(b2)
+    np.testing.assert_array_equal(ay.bbox_iou(t1, t2).numpy(), z["iou_rand"])
+    np.testing.assert_array_equal(ay.bbox_iou(t1, t2, x1y1x2y2=False).numpy(), z["iou_rand_c"])
+    np.testing.assert_array_equal(ay.bbox_iou(t1[:1], t2).numpy(), z["iou_bcast"])
+    np.testing.assert_array_equal(ay.xywh2xyxy(t1).numpy(), z["xyxy"])
+    kat = ay.bbox_iou(torch.tensor([[100., 100, 200, 200]]), torch.tensor([[150., 150, 200, 200], [201, 201, 300, 300], [100, 100, 200, 200]]))
+    np.testing.assert_array_equal(kat.numpy(), z["iou"])
+    np.testing.assert_array_equal(ay.bbox_wh_iou(torch.tensor([3., 4.]), torch.tensor([[3., 4], [6, 2], [1, 1]])).numpy(), z["whiou"])
+    # pairwise + GIoU against the oracle (GIoU: parity unpinned by the reference, checked against the oracle only)
+    pw = ay.bbox_iou_pairwise(t1[:40], t2[:50]).numpy()
+    ref = np.stack([bo.bbox_iou(b1[i:i + 1], b2[:50]) for i in range(40)])
+    np.testing.assert_array_equal(pw, ref)
+    close(ay.bbox_iou(t1, t2, giou=True).numpy(), bo.bbox_giou(b1, b2), 1e-6)
+    rb = ay.rescale_boxes(torch.tensor([[10., 20, 200, 300, .9, .8, 1], [50, 60, 70, 80, .5, .5, 0]]), 416, (1536, 1024))
+    close(rb.numpy(), z["rescale"], 1e-6)
+
+
+# ----------------------------------------------------------------------------------------- decode
+def test_decode_kat_and_heads(golden_dir, dev):
+    L = _lib.lib()
+    z = load(golden_dir, "kat")
+    p = torch.zeros(1, 21, 2, 2)
+    p[0, 0, 1, 0], p[0, 9, 0, 1], p[0, 18, 1, 1] = 1.0, 0.5, 2.0
+    out = torch.empty(1, 12, 7, device=dev)
+    an = (C.c_float * 6)(10, 13, 16, 30, 33, 23)
+    check(L.ay_yolo_decode(ptr(p.to(dev)), 0, ptr(out), 1, 3, 2, 2, 64, an, 12, 0, _lib.stream_ptr()))
+    close(out.cpu().numpy(), z["decode"], 1e-6)
+    # real head tensors of the S=96, C=3 fixture, all three scales into one output tensor
+    zz = load(golden_dir, "model_c3_s96_b2")
+    anchors = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+    N = zz["out"].shape[1]
+    out = torch.zeros(2, N, 8, device=dev)
+    row = 0
+    for j in range(3):
+        h = torch.from_numpy(zz[f"head{j}"]).to(dev)
+        G = h.shape[2]
+        an = (C.c_float * 6)(*[float(v) for a in anchors[j] for v in a])
+        check(L.ay_yolo_decode(ptr(h), 0, ptr(out), 2, 3, 3, G, 96, an, N, row, _lib.stream_ptr()))
+        row += 3 * G * G
+    close(out.cpu().numpy(), zz["out"], 1e-5)
+
+
+# ----------------------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize("name", [c[0] for c in gc.NMS_CASES])
+def test_nms_golden(golden_dir, dev, name):
+    z = load(golden_dir, "nms_" + name)
+    pred, conf_t, nms_t = gc.nms_case_inputs(name)
+    t = torch.from_numpy(pred.copy())
+    res = ay.non_max_suppression(t, conf_t, nms_t)            # host tensor in, host rows out
+    np.testing.assert_array_equal(t.numpy()[0, :8], z["corners0"])  # in-place corner conversion, bit-exact
+    o_rows, o_keep, _ = bo.non_max_suppression(pred.copy(), conf_t, nms_t)
+    for b in range(pred.shape[0]):
+        n = int(z[f"n{b}"])
+        if n == 0:
+            assert res[b] is None
+            continue
+        np.testing.assert_array_equal(res.keep_idx[b], z[f"keep{b}"])      # bit-exact box indices (reference)
+        np.testing.assert_array_equal(res.keep_idx[b], o_keep[b])          # and the oracle agrees
+        got = res[b].numpy()
+        close(got, z[f"rows{b}"], 1e-5, name)
+        np.testing.assert_array_equal(got[:, 4:], z[f"rows{b}"][:, 4:])    # conf / cls columns untouched
+
+
+def test_nms_device_tensor_and_large(dev):
+    """device-resident input; 20k candidates exercises the workspace (non-LDS) sort path."""
+    pred = gc.nms_prediction(30000, [20000], 3, 41, conf_thres=0.3)
+    sc = pred[0][pred[0, :, 4] >= 0.3]
+    assert np.unique(sc[:, 4] * sc[:, 5:].max(1)).size == sc.shape[0]
+    o_rows, o_keep, _ = bo.non_max_suppression(pred.copy(), 0.3, 0.45)
+    t = torch.from_numpy(pred.copy()).to(dev)
+    res = ay.non_max_suppression(t, 0.3, 0.45)
+    assert res[0].is_cuda
+    np.testing.assert_array_equal(res.keep_idx[0], o_keep[0])
+    close(res[0].cpu().numpy(), o_rows[0], 1e-5)
+    assert int(res.cand_count[0]) == 20000
+
+
+# ----------------------------------------------------------------------------------------- conv kernels
+def _bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, H, leaky, residual, out_f32
+    (32, 64, 3, 1, 40, True, True, False),      # BN=64 tile, ragged 40 (not a multiple of 32)
+    (64, 128, 3, 1, 32, True, False, False),    # BN=128
+    (128, 256, 3, 1, 13, True, True, False),    # 416/32 grid: heavy masking
+    (32, 64, 3, 2, 64, True, False, False),     # stride 2, BN=64
+    (128, 256, 3, 2, 26, True, False, False),   # stride 2, BN=128, ragged
+    (64, 32, 1, 1, 52, True, False, False),     # 1x1 BN=32, NK=4
+    (256, 128, 1, 1, 26, True, False, False),   # 1x1 BN=128
+    (1024, 24, 1, 1, 13, False, False, True),   # linear head, f32 out, cout pad 24->32
+    (256, 255, 1, 1, 8, False, False, True),    # COCO-sized head, 255->256
+    (48, 96, 1, 1, 16, True, False, False),     # cin not a multiple of 64 (NK=1 path)
+    (512, 1024, 3, 1, 8, True, True, False),    # deep K loop
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_bf16_kernel(dev, case):
+    """bf16 MFMA block vs torch-CPU fp32 conv of the bf16-rounded operands (+affine, leaky, residual), rounded once.
+    Tolerance: 1 bf16 ulp of the result (2^-8 relative) + 1e-3 absolute for accumulation-order noise."""
+    cin, cout, k, stride, H, leaky, has_res, out_f32 = case
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    B = 2
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + H)
+    x = _bf16r(torch.randn(B, cin, H, H, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = _bf16r(torch.randn(B, cout, Ho, Ho, generator=g)) if has_res else None
+    ref = F.conv2d(x, _bf16r(w), None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if leaky:
+        ref = F.leaky_relu(ref, 0.1)
+    if has_res:
+        ref = ref + res
+    cpad = (cout + 31) // 32 * 32
+    xb = torch.empty(B, cin // 16, H, H, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(x.to(dev)), ptr(xb), B, cin, H, H, st))
+    packed = torch.empty(L.ay_packed_weight_bytes(cpad, cin, k), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_conv_weights_bf16(ptr(w.to(dev)), ptr(packed), cout, cpad, cin, k, st))
+    sc = torch.zeros(cpad, device=dev)
+    sh = torch.zeros(cpad, device=dev)
+    sc[:cout], sh[:cout] = scale.to(dev), shift.to(dev)
+    rb = None
+    if has_res:
+        rb = torch.empty(B, cpad // 16, Ho, Ho, 16, device=dev, dtype=torch.bfloat16)
+        check(L.ay_nchw_f32_to_blocked_bf16(ptr(res.to(dev)), ptr(rb), B, cout, Ho, Ho, st))
+    ob = torch.full((B, cpad // 16, Ho, Ho, 16), float("nan"), device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    d = ConvDesc(B, cin, cout, H, H, Ho, Ho, k, stride, int(leaky), int(out_f32), cpad)
+    check(L.ay_conv_fwd_bf16(C.byref(d), ptr(xb), ptr(packed), ptr(sc), ptr(sh), ptr(rb), ptr(ob), st), "conv")
+    got = torch.empty(B, cout, Ho, Ho, device=dev)
+    fn = L.ay_blocked_f32_to_nchw_f32 if out_f32 else L.ay_blocked_bf16_to_nchw_f32
+    check(fn(ptr(ob), ptr(got), B, cout, Ho, Ho, st))
+    got = got.cpu()
+    assert torch.isfinite(got).all()
+    if not out_f32:
+        ref = _bf16r(ref)
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-3
+    assert bool((err <= bound).all()), float((err - bound).max())
+    if cpad > cout:  # padded channels come out as exact zeros (scale = shift = 0 there)
+        full = torch.empty(B, cpad, Ho, Ho, device=dev)
+        check(fn(ptr(ob), ptr(full), B, cpad, Ho, Ho, st))
+        assert float(full[:, cout:].abs().max()) == 0.0
+
+
+def test_stem_and_concat(dev):
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(5)
+    B, H = 2, 70
+    x = torch.rand(B, 3, H, H, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    ref = _bf16r(F.leaky_relu(F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1))
+    ob = torch.empty(B, 2, H, H, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_stem_conv_fwd(ptr(x.to(dev)), ptr(w.to(dev)), ptr(scale.to(dev)), ptr(shift.to(dev)), ptr(ob), B, H, H, 1, st))
+    got = torch.empty(B, 32, H, H, device=dev)
+    check(L.ay_blocked_bf16_to_nchw_f32(ptr(ob), ptr(got), B, 32, H, H, st))
+    err = (got.cpu() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-5).all())
+    # route + upsample gather is a pure copy: bit-exact
+    a = _bf16r(torch.randn(B, 32, 6, 6, generator=g))
+    b_ = _bf16r(torch.randn(B, 48, 12, 12, generator=g))
+    ab = torch.empty(B, 2, 6, 6, 16, device=dev, dtype=torch.bfloat16)
+    bb = torch.empty(B, 3, 12, 12, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(a.to(dev)), ptr(ab), B, 32, 6, 6, st))
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(b_.to(dev)), ptr(bb), B, 48, 12, 12, st))
+    ob = torch.empty(B, 5, 12, 12, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_concat_upsample_bf16(ptr(ab), 32, 1, ptr(bb), 48, ptr(ob), B, 12, 12, st))
+    got = torch.empty(B, 80, 12, 12, device=dev)
+    check(L.ay_blocked_bf16_to_nchw_f32(ptr(ob), ptr(got), B, 80, 12, 12, st))
+    ref = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), b_], 1)
+    assert torch.equal(got.cpu(), ref)
+
+
+# ----------------------------------------------------------------------------------------- whole model
+_models = {}
+
+
+def build_models(C_, cfg_dir, dev, precision):
+    key = (C_, precision)
+    if key not in _models:
+        cfg = cfg_gen.write_cfg(C_, cfg_dir)
+        defs = parse_config.parse_model_config(cfg)
+        params = synth.synth_params(defs, seed=7)
+        wpath = os.path.join(cfg_dir, f"synth_c{C_}.weights")
+        if not os.path.exists(wpath):
+            synth.write_darknet_weights(wpath, defs, params, seen=12345)
+        m = Darknet(cfg, precision=precision).to(dev).eval()
+        m.load_darknet_weights(wpath)              # through the Darknet .weights format boundary
+        o = OracleDarknet(cfg)
+        o.set_params(params)
+        _models[key] = (m, o)
+    return _models[key]
+
+
+@pytest.mark.parametrize("case", gc.MODEL_CASES, ids=lambda c: c[0])
+def test_model_fp32_vs_reference_fixtures(golden_dir, tmp_cfg_dir, dev, case):
+    """precision='fp32' HIP path == the reference's CPU path: boxes within 1e-4, NMS indices bit-exact."""
+    name, C_, S, B, start = case
+    z = load(golden_dir, "model_" + name)
+    m, _ = build_models(C_, tmp_cfg_dir, dev, "fp32")
+    m.keep_layer_outputs = True
+    x = torch.from_numpy(gc.model_inputs(S, B, start))
+    out = m(x)
+    assert not out.is_cuda and out.shape == (B, m.num_boxes(S), 5 + C_)
+    if "out" in z:
+        close(out.numpy(), z["out"], TOL, "boxes")
+    else:
+        close(out.numpy()[:, z["out_rows"]], z["out_sel"], TOL, "boxes")
+    for k, li in enumerate(z["layer_idx"]):
+        li = int(li)
+        if li not in m.layer_outputs:
+            continue  # conv fused into the following shortcut: its own output is never materialised
+        f = m.layer_output_nchw(li).cpu().numpy().reshape(-1)
+        close(f[z["samp_idx"][k]], z["samp_val"][k], TOL, f"layer {li}")
+    res = ay.non_max_suppression(out, 0.5, 0.4)
+    for b in range(B):
+        n = int(z[f"nms_n{b}"])
+        assert (0 if res[b] is None else res[b].shape[0]) == n
+        if n:
+            np.testing.assert_array_equal(res.keep_idx[b], z[f"nms_keep{b}"])   # bit-exact box indices after NMS
+            close(res[b].numpy(), z[f"nms_rows{b}"], TOL, "nms rows")
+    m.keep_layer_outputs = False
+
+
+@pytest.mark.parametrize("case", [c for c in gc.MODEL_CASES if c[2] <= 416], ids=lambda c: c[0])
+def test_model_bf16_vs_bf16_oracle(tmp_cfg_dir, dev, case):
+    """bf16 MFMA path vs the oracle run with the same rounding points (mode='bf16').  Per layer: every stored
+    activation within 2 bf16 ulps (2^-7 relative) + 0.02 absolute of the oracle's (accumulation order moves a
+    value across a rounding boundary now and then, and the error compounds over 75 layers); heads likewise."""
+    name, C_, S, B, start = case
+    m, o = build_models(C_, tmp_cfg_dir, dev, "bf16")
+    m.keep_layer_outputs = True
+    x = torch.from_numpy(gc.model_inputs(S, B, start))
+    out = m(x).numpy()
+    with torch.no_grad():
+        ref = o.forward(x, mode="bf16", collect=True).numpy()
+    worst = 0.0
+    for li, t in sorted(m.layer_outputs.items()):
+        if m._graph[li]["type"] not in ("convolutional", "shortcut", "route"):
+            continue
+        got = m.layer_output_nchw(li).cpu()
+        want = o.layer_outputs[li]
+        err = (got - want).abs()
+        bound = want.abs() * 2.0 ** -7 + 0.02
+        frac_bad = float((err > bound).float().mean())
+        worst = max(worst, frac_bad)
+        assert frac_bad <= 1e-3, (li, frac_bad, float(err.max()))
+    # decoded boxes: conf/cls are sigmoids (abs 2e-2), coordinates relative 2e-2 of the box scale
+    assert np.abs(out[..., 4:] - ref[..., 4:]).max() <= 3e-2
+    box_scale = np.maximum(1.0, ref[..., 2:4].max(-1, keepdims=True))
+    rel = np.abs(out[..., :4] - ref[..., :4]) / box_scale
+    assert np.quantile(rel, 0.999) <= 5e-2, float(np.quantile(rel, 0.999))
+    m.keep_layer_outputs = False
