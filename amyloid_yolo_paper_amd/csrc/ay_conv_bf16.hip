@@ -235,28 +235,23 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
                 } else {
                     const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
                     if constexpr (HAS_RES) {
-                        // swap in fp32 so the residual is added before the single bf16 rounding
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[j]),
-                                                                      __builtin_bit_cast(unsigned, w[j]), false, false);
-                            v[j] = __builtin_bit_cast(float, r[0]);
-                            w[j] = __builtin_bit_cast(float, r[1]);
-                        }
+                        // residual read in the accumulator's own layout (8 B per quad), added in fp32 before the
+                        // single bf16 rounding; out-of-tile lanes skip the load
                         if (ok) {
-                            const uint4 rr = *reinterpret_cast<const uint4*>(a.residual + ob);
-                            const unsigned rv[4] = {rr.x, rr.y, rr.z, rr.w};
-                            float f[8] = {v[0], v[1], v[2], v[3], w[0], w[1], w[2], w[3]};
-                            unsigned o[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float lo = f[2 * j] + bf2f((uint16_t)(rv[j] & 0xffffu));
-                                const float hi = f[2 * j + 1] + bf2f((uint16_t)(rv[j] >> 16));
-                                o[j] = pack2bf(lo, hi);
-                            }
-                            *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(o[0], o[1], o[2], o[3]);
+                            const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
+                            const uint2 r0v = *reinterpret_cast<const uint2*>(rp);
+                            const uint2 r1v = *reinterpret_cast<const uint2*>(rp + 16);
+                            v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
+                            v[1] += bf2f((uint16_t)(r0v.x >> 16));
+                            v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
+                            v[3] += bf2f((uint16_t)(r0v.y >> 16));
+                            w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
+                            w[1] += bf2f((uint16_t)(r1v.x >> 16));
+                            w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
+                            w[3] += bf2f((uint16_t)(r1v.y >> 16));
                         }
-                    } else {
+                    }
+                    {
                         unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
                         unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
                         auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);

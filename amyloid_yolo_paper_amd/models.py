@@ -112,7 +112,7 @@ class Darknet(nn.Module):
         self.precision = precision
         self._graph = self._analyse()
         self._prep = None       # packed weights / folded BN, keyed by parameter versions
-        self._buffers = {}      # (precision, B, S) -> per-layer device tensors
+        self._act_bufs = {}      # (precision, B, S) -> per-layer device tensors
         self.keep_layer_outputs = False
         self.layer_outputs = None
 
@@ -298,7 +298,7 @@ class Darknet(nn.Module):
         st = _lib.stream_ptr()
         bf16 = self.precision == "bf16"
         key = (self.precision, B, S)
-        bufs = self._buffers.setdefault(key, {})
+        bufs = self._act_bufs.setdefault(key, {})
         C_ = self.yolo_layers[0].num_classes
         N = self.num_boxes(S)
         if "out" not in bufs:
