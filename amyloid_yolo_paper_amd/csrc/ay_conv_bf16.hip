@@ -16,6 +16,8 @@
 //   weights      [Cin/16][tap][half][CoutPad][8] bf16   (half = input channels 0-7 / 8-15 of the chunk)
 //   LDS pixels   [kstep][half][IN_PIX][8 bf16]  -> lane (pixel c, half h) reads 16 B, conflict-free
 //   LDS filters  [kstep][tap][half][BN][8 bf16]
+#include <stdlib.h>
+
 #include "ay_common.h"
 
 namespace ay {
@@ -31,6 +33,87 @@ struct ConvArgs {
     int tiles_x, tiles_y, n_cgroups;
     int leaky;
 };
+
+// ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
+// C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
+// v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
+template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int cg, int wm, int wn, int c,
+                                              int hh, int y0, int x0) {
+    const int CP = a.cout_pad;
+    const size_t out_plane_px = (size_t)a.hout * a.wout;
+    const int cbase = cg * BN + wm * MT * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int oy = y0 + p / TW, ox = x0 + p % TW;
+        const bool ok = (oy < a.hout) && (ox < a.wout);
+        const size_t pix = (size_t)oy * a.wout + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
+                const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
+                float v[4], w[4];
+                {
+                    const float4 s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
+                    const float4 t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
+                    const float4 s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
+                    const float4 t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
+                    const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
+                    const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x0v = acc[m][n][(2 * qp) * 4 + j] * ss0[j] + tt0[j];
+                        float x1v = acc[m][n][(2 * qp + 1) * 4 + j] * ss1[j] + tt1[j];
+                        if (a.leaky) {
+                            x0v = x0v > 0.f ? x0v : 0.1f * x0v;
+                            x1v = x1v > 0.f ? x1v : 0.1f * x1v;
+                        }
+                        v[j] = x0v;
+                        w[j] = x1v;
+                    }
+                }
+                const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
+                if constexpr (OUT_F32) {
+                    // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
+                    if (ok) {
+                        float* o = reinterpret_cast<float*>(a.out) + (plane * out_plane_px + pix) * 16;
+                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w[0], w[1], w[2], w[3]);
+                    }
+                } else {
+                    const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
+                    if constexpr (HAS_RES) {
+                        // residual read in the accumulator's own layout (8 B per quad), added in fp32 before the
+                        // single bf16 rounding; out-of-tile lanes skip the load
+                        if (ok) {
+                            const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
+                            const uint2 r0v = *reinterpret_cast<const uint2*>(rp);
+                            const uint2 r1v = *reinterpret_cast<const uint2*>(rp + 16);
+                            v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
+                            v[1] += bf2f((uint16_t)(r0v.x >> 16));
+                            v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
+                            v[3] += bf2f((uint16_t)(r0v.y >> 16));
+                            w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
+                            w[1] += bf2f((uint16_t)(r1v.x >> 16));
+                            w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
+                            w[3] += bf2f((uint16_t)(r1v.y >> 16));
+                        }
+                    }
+                    {
+                        unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
+                        unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
+                        if (ok) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
@@ -187,84 +270,183 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
         }
     }
 
-    // ---- epilogue: affine + leaky (+ residual) -> direct stores -----------------------------------
-    // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
-    // v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
-    const size_t out_plane_px = (size_t)a.hout * a.wout;
-    const int cbase = cg * BN + wm * MT * 32;
+    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, b, cg, wm, wn, c, hh, y0, x0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// V2: 8 waves (512 threads), one workgroup per CU, two LDS stage buffers.
+//   * filters go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write); the LDS image
+//     [tap][half][BN][16 B] is exactly the lane-linear order the DMA writes;
+//   * the input halo tile goes through registers (border pixels need zero fill) and is written into the other
+//     buffer after the MFMAs of the current stage;
+//   * one barrier per 16-channel stage; the DMA of stage s+1 is in flight during the MFMAs of stage s.
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2) conv_bf16_dma_kernel(ConvArgs a) {
+    constexpr int NTHR = 512;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int KK2 = KS * KS;
+    constexpr int NPIX = TH * TW;
+    constexpr int NT = NPIX / (WN * 32);
+    constexpr int MT = BN / (WM * 32);
+    constexpr int IN_H = (TH - 1) * STRIDE + KS;
+    constexpr int IN_W = (TW - 1) * STRIDE + KS;
+    constexpr int IN_PIX = IN_H * IN_W;
+    constexpr int PIX_SLAB = 2 * IN_PIX * 16;
+    constexpr int W_SLAB = KK2 * 2 * BN * 16;
+    constexpr int W_BASE = NK * PIX_SLAB;
+    constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
+    constexpr int PXU_TOTAL = NK * 2 * IN_PIX;
+    constexpr int NPXU = (PXU_TOTAL + NTHR - 1) / NTHR;
+    constexpr int WU_TOTAL = NK * KK2 * 2 * BN;
+    constexpr int NWU = (WU_TOTAL + NTHR - 1) / NTHR;
+    static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
+    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
+    static_assert(WU_TOTAL % 64 == 0, "filter DMA pieces are whole waves");
+    static_assert(2 * BUF_BYTES <= 160 * 1024, "two stage buffers per CU");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int c = lane & 31, hh = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int cg = bid % a.n_cgroups;
+    const int pt = bid / a.n_cgroups;
+    const int tile_x = pt % a.tiles_x;
+    const int tile_y = (pt / a.tiles_x) % a.tiles_y;
+    const int b = pt / (a.tiles_x * a.tiles_y);
+    const int y0 = tile_y * TH, x0 = tile_x * TW;
+
+    const size_t in_plane = (size_t)a.hin * a.win * 32;
+    const uint8_t* src_img = a.src + (size_t)b * (a.cin / 16) * in_plane;
+    const int CP = a.cout_pad;
+    const uint8_t* wbase = a.w + (size_t)cg * BN * 16;
+    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
+
+    int px_off[NPXU];
+#pragma unroll
+    for (int i = 0; i < NPXU; ++i) {
+        const int u = i * NTHR + tid;
+        int off = -1;
+        if (u < PXU_TOTAL) {
+            const int kk = u / (2 * IN_PIX);
+            const int v = u % (2 * IN_PIX);
+            const int P = v >> 1, h = v & 1;
+            const int iy = y0 * STRIDE - PAD + P / IN_W;
+            const int ix = x0 * STRIDE - PAD + P % IN_W;
+            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+        }
+        px_off[i] = off;
+    }
+    // per-lane source offset of filter DMA piece i inside one stage (piece = 64 lanes x 16 B = 1 KiB of the LDS image)
+    int w_off[NWU];
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+        const int u = i * NTHR + tid;
+        const int r = u % BN, th = u / BN;
+        w_off[i] = (th * CP + r) * 16;
+    }
+
+    uint4 rpx[NPXU];
+
+    auto dma_filters = [&](int s, int buf) {
+        const uint8_t* wp = wbase + (size_t)s * w_stage_stride;
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            if (i * NTHR + wave * 64 < WU_TOTAL) {  // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + w_off[i]),
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * BUF_BYTES + W_BASE +
+                                                                                           (i * NTHR + wave * 64) * 16),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    auto load_pixels = [&](int s) {
+        const uint8_t* sp = src_img + (size_t)s * NK * in_plane;
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (px_off[i] >= 0) v = *reinterpret_cast<const uint4*>(sp + px_off[i]);
+            rpx[i] = v;
+        }
+    };
+    auto store_pixels = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            const int u = i * NTHR + tid;
+            if (u < PXU_TOTAL) {
+                const int kk = u / (2 * IN_PIX);
+                const int v = u % (2 * IN_PIX);
+                const int P = v >> 1, h = v & 1;
+                *reinterpret_cast<uint4*>(lds + buf * BUF_BYTES + kk * PIX_SLAB + (h * IN_PIX + P) * 16) = rpx[i];
+            }
+        }
+    };
+
+    int pb[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
-        const int oy = y0 + p / TW, ox = x0 + p % TW;
-        const bool ok = (oy < a.hout) && (ox < a.wout);
-        const size_t pix = (size_t)oy * a.wout + ox;
+        const int ty = p / TW, tx = p % TW;
+        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
+    }
+    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
-                const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
-                float v[4], w[4];
-                {
-                    const float4 s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
-                    const float4 t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
-                    const float4 s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
-                    const float4 t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
-                    const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
-                    const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x0v = acc[m][n][(2 * qp) * 4 + j] * ss0[j] + tt0[j];
-                        float x1v = acc[m][n][(2 * qp + 1) * 4 + j] * ss1[j] + tt1[j];
-                        if (a.leaky) {
-                            x0v = x0v > 0.f ? x0v : 0.1f * x0v;
-                            x1v = x1v > 0.f ? x1v : 0.1f * x1v;
-                        }
-                        v[j] = x0v;
-                        w[j] = x1v;
-                    }
-                }
-                const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
-                if constexpr (OUT_F32) {
-                    // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
-                    if (ok) {
-                        float* o = reinterpret_cast<float*>(a.out) + (plane * out_plane_px + pix) * 16;
-                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w[0], w[1], w[2], w[3]);
-                    }
-                } else {
-                    const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
-                    if constexpr (HAS_RES) {
-                        // residual read in the accumulator's own layout (8 B per quad), added in fp32 before the
-                        // single bf16 rounding; out-of-tile lanes skip the load
-                        if (ok) {
-                            const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                            const uint2 r0v = *reinterpret_cast<const uint2*>(rp);
-                            const uint2 r1v = *reinterpret_cast<const uint2*>(rp + 16);
-                            v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
-                            v[1] += bf2f((uint16_t)(r0v.x >> 16));
-                            v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
-                            v[3] += bf2f((uint16_t)(r0v.y >> 16));
-                            w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
-                            w[1] += bf2f((uint16_t)(r1v.x >> 16));
-                            w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
-                            w[3] += bf2f((uint16_t)(r1v.y >> 16));
-                        }
-                    }
-                    {
-                        unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
-                        unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
-                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
-                        if (ok) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                    }
-                }
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int nstages = a.cin / (16 * NK);
+    dma_filters(0, 0);
+    load_pixels(0);
+    store_pixels(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int cur = s & 1;
+        const bool more = (s + 1 < nstages);
+        if (more) {
+            load_pixels(s + 1);
+            dma_filters(s + 1, cur ^ 1);
+        }
+        const uint8_t* L = lds + cur * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+#pragma unroll
+            for (int tap = 0; tap < KK2; ++tap) {
+                const int kh = tap / KS, kw = tap % KS;
+                bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    af[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bfr[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
             }
         }
+        if (more) {
+            store_pixels(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter DMA of stage s+1 has landed
+            __syncthreads();
+        }
     }
+    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, b, cg, wm, wn, c, hh, y0, x0);
 }
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
 static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
                   const void* residual, void* out, hipStream_t st) {
     ConvArgs a;
@@ -290,8 +472,14 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         set_error("conv grid out of range (%lld)", nblk);
         return AY_ERR_ARG;
     }
-    dim3 grid((unsigned)nblk), block(256);
-    if constexpr (OUT_F32) {
+    dim3 grid((unsigned)nblk), block(V2 ? 512 : 256);
+    if constexpr (V2) {
+        static_assert(!OUT_F32 || !V2, "V2 is instantiated for bf16 outputs only");
+        if (residual)
+            hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
+    } else if constexpr (OUT_F32) {
         hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false>), grid, block, 0, st, a);
     } else {
         if (residual)
@@ -321,6 +509,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     const int cp = d->cout_pad;
     if (d->ksize == 3 && d->stride == 1) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
+        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;  // A/B switch for benchmarking
+        if (cp % 128 == 0 && !v1) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0 && !v1) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<3, 1, 128, 2, 2, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0) return launch<3, 1, 64, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<3, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);

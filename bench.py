@@ -168,33 +168,49 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, cfg, params):
-    """The CPU oracle (port of the reference's CPU path) on a bounded sample: `cpu_tiles` tiles, batch 1, all host cores."""
-    import torch
-    from amyloid_yolo_paper_amd import synth
-    from oracle import boxes_oracle as bo
-    from oracle.darknet_oracle import OracleDarknet
+def host_cores():
+    """threads the CPU baseline may use: scheduler affinity, clipped by the cgroup CPU quota of this box"""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(cores, int(os.environ.get("AY_CPU_THREADS", "16"))))  # GPU boxes give 16 CPUs per GPU
+
+
+def cpu_baseline(a, cfg, params):
+    """The CPU oracle (port of the reference's CPU path) on a bounded sample of the same tiles: batch 1, as many
+    tiles as fit in ~20 s (at most --cpu_tiles), on the host cores of this box."""
+    import torch
+    from amyloid_yolo_paper_amd import synth
+    from oracle import boxes_oracle as bo
+    from oracle.darknet_oracle import OracleDarknet
+    cores = host_cores()
     torch.set_num_threads(cores)
     m = OracleDarknet(cfg)
     m.set_params(params)
     tiles = torch.from_numpy(synth.synth_tiles(a.cpu_tiles, a.size, start=0))
     with torch.no_grad():
-        m.forward(tiles[:1])  # warm
+        tw = time.perf_counter()
+        m.forward(tiles[:1])  # warm-up, also sizes the sample
+        warm = time.perf_counter() - tw
+        n = max(1, min(a.cpu_tiles, int(20.0 / max(warm, 1e-3))))
         t0 = time.perf_counter()
         t_nms = 0.0
-        for i in range(a.cpu_tiles):
+        for i in range(n):
             out = m.forward(tiles[i:i + 1]).numpy()
             t2 = time.perf_counter()
             bo.non_max_suppression(out, a.conf_thres, a.nms_thres)
             t_nms += time.perf_counter() - t2
         dt = time.perf_counter() - t0
-    return {"value": round(a.cpu_tiles / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{a.cpu_tiles} of the same synthetic {a.size}x{a.size} tiles, batch 1, fp32 torch-CPU conv stack + restated decode/merge-NMS "
+    return {"value": round(n / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the same synthetic {a.size}x{a.size} tiles, batch 1, fp32 torch-CPU conv stack + restated decode/merge-NMS "
                       f"({dt:.1f} s total, NMS {t_nms:.2f} s)"}
 
 
