@@ -518,6 +518,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     }
     if (d->ksize == 3 && d->stride == 2) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
+        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;
+        if (cp % 128 == 0 && !v1) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0 && !v1) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<3, 2, 128, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0) return launch<3, 2, 64, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<3, 2, 32, 1, 4, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
@@ -528,6 +531,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
             return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
         }
+        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;
+        if (cp % 128 == 0 && !v1) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0 && !v1) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<1, 1, 128, 2, 2, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<1, 1, 32, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
