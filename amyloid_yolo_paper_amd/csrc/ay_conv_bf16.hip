@@ -32,15 +32,54 @@ struct ConvArgs {
     int batch, cin, cout_pad, hin, win, hout, wout;
     int tiles_x, tiles_y, n_cgroups;
     int leaky;
+    int dbg;  // timing experiments only (AY_DBG): 1 = no staging in the stage loop, 2 = no MFMA phase
 };
 
 // ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
 // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
 // v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
-template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int cg, int wm, int wn, int c,
-                                              int hh, int y0, int x0) {
+// residual operand of one wave tile, in the accumulator's own layout: [m][n][quad pair][quad] x 8 bytes
+template <int MT, int NT>
+struct ResRegs {
+    uint2 r[MT][NT][2][2];
+};
+
+template <int BN, int MT, int NT, int TW, bool HAS_RES>
+__device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT, NT>& rr, int b, int cg, int wm, int wn, int c,
+                                                  int hh, int y0, int x0) {
+    if constexpr (HAS_RES) {
+        const int CP = a.cout_pad;
+        const size_t out_plane_px = (size_t)a.hout * a.wout;
+        const int cbase = cg * BN + wm * MT * 32;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int p = (wn * NT + n) * 32 + c;
+            const int oy = y0 + p / TW, ox = x0 + p % TW;
+            const bool ok = (oy < a.hout) && (ox < a.wout);
+            const size_t pix = (size_t)oy * a.wout + ox;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    const int ch0 = cbase + m * 32 + qp * 16;
+                    const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
+                    uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
+                    if (ok) {
+                        const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
+                        v0 = *reinterpret_cast<const uint2*>(rp);
+                        v1 = *reinterpret_cast<const uint2*>(rp + 16);
+                    }
+                    rr.r[m][n][qp][0] = v0;
+                    rr.r[m][n][qp][1] = v1;
+                }
+        }
+    }
+}
+
+template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
+                                              int wm, int wn, int c, int hh, int y0, int x0) {
     const int CP = a.cout_pad;
     const size_t out_plane_px = (size_t)a.hout * a.wout;
     const int cbase = cg * BN + wm * MT * 32;
@@ -86,21 +125,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 } else {
                     const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
                     if constexpr (HAS_RES) {
-                        // residual read in the accumulator's own layout (8 B per quad), added in fp32 before the
-                        // single bf16 rounding; out-of-tile lanes skip the load
-                        if (ok) {
-                            const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                            const uint2 r0v = *reinterpret_cast<const uint2*>(rp);
-                            const uint2 r1v = *reinterpret_cast<const uint2*>(rp + 16);
-                            v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
-                            v[1] += bf2f((uint16_t)(r0v.x >> 16));
-                            v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
-                            v[3] += bf2f((uint16_t)(r0v.y >> 16));
-                            w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
-                            w[1] += bf2f((uint16_t)(r1v.x >> 16));
-                            w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
-                            w[3] += bf2f((uint16_t)(r1v.y >> 16));
+                        // residual (prefetched in the accumulator's own layout) added in fp32 before the single rounding
+                        uint2 r0v, r1v;
+                        if constexpr (RES_INLINE) {  // large wave tiles: no room to hold the whole residual in registers
+                            r0v = r1v = make_uint2(0, 0);
+                            if (ok) {
+                                const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
+                                r0v = *reinterpret_cast<const uint2*>(rp);
+                                r1v = *reinterpret_cast<const uint2*>(rp + 16);
+                            }
+                        } else {
+                            r0v = rr.r[m][n][qp][0];
+                            r1v = rr.r[m][n][qp][1];
                         }
+                        v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
+                        v[1] += bf2f((uint16_t)(r0v.x >> 16));
+                        v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
+                        v[3] += bf2f((uint16_t)(r0v.y >> 16));
+                        w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
+                        w[1] += bf2f((uint16_t)(r1v.x >> 16));
+                        w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
+                        w[3] += bf2f((uint16_t)(r1v.y >> 16));
                     }
                     {
                         unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
@@ -270,7 +315,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
         }
     }
 
-    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, b, cg, wm, wn, c, hh, y0, x0);
+    ResRegs<MT, NT> rr;
+    residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -443,7 +490,476 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_dma_kernel(ConvArgs a) {
             __syncthreads();
         }
     }
-    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, b, cg, wm, wn, c, hh, y0, x0);
+    ResRegs<MT, NT> rr;
+    residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// V3: V2's stage pipeline made persistent.  One workgroup per CU walks a list of (pixel tile, channel group)
+// items; the stage pipeline runs straight across item boundaries (the first stage of the next item is loaded
+// during the last stage of the current one), the residual operand is prefetched during the last stage, and
+// the epilogue's stores drain while the next item computes.  Items are dealt so that the workgroups that share
+// an XCD (blockIdx % 8, observed round-robin placement: speed only) walk one contiguous range of items, channel
+// groups of a pixel tile adjacent, so its input halo and the filters stay in that XCD's L2.
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, int n_items) {
+    constexpr int NTHR = 512;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int KK2 = KS * KS;
+    constexpr int NPIX = TH * TW;
+    constexpr int NT = NPIX / (WN * 32);
+    constexpr int MT = BN / (WM * 32);
+    constexpr int IN_H = (TH - 1) * STRIDE + KS;
+    constexpr int IN_W = (TW - 1) * STRIDE + KS;
+    constexpr int IN_PIX = IN_H * IN_W;
+    constexpr int PIX_SLAB = 2 * IN_PIX * 16;
+    constexpr int W_SLAB = KK2 * 2 * BN * 16;
+    constexpr int W_BASE = NK * PIX_SLAB;
+    constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
+    constexpr int PXU_TOTAL = NK * 2 * IN_PIX;
+    constexpr int NPXU = (PXU_TOTAL + NTHR - 1) / NTHR;
+    constexpr int WU_TOTAL = NK * KK2 * 2 * BN;
+    constexpr int NWU = (WU_TOTAL + NTHR - 1) / NTHR;
+    static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
+    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
+    static_assert(WU_TOTAL % 64 == 0, "filter DMA pieces are whole waves");
+    static_assert(2 * BUF_BYTES <= 160 * 1024, "two stage buffers per CU");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int c = lane & 31, hh = lane >> 5;
+
+    // ---- item list of this workgroup -----------------------------------------------------------------
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int per_xcd = (n_items + 7) >> 3;
+    const int first = xcd * per_xcd;
+    const int last = min(first + per_xcd, n_items);
+    int item = first + slot;
+    if (item >= last) return;
+
+    const size_t in_plane = (size_t)a.hin * a.win * 32;
+    const int CP = a.cout_pad;
+    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+    // loader state (runs one stage ahead of the MFMAs, possibly already in the next item)
+    int px_off[NPXU];
+    const uint8_t* ld_src;
+    const uint8_t* ld_w;
+    auto setup_loader = [&](int it) {
+        const int cg = it % a.n_cgroups;
+        const int pt = it / a.n_cgroups;
+        const int b = pt / tiles_per_img;
+        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
+        ld_src = a.src + (size_t)b * (a.cin / 16) * in_plane;
+        ld_w = a.w + (size_t)cg * BN * 16;
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            const int u = i * NTHR + tid;
+            int off = -1;
+            if (u < PXU_TOTAL) {
+                const int kk = u / (2 * IN_PIX);
+                const int v = u % (2 * IN_PIX);
+                const int P = v >> 1, h = v & 1;
+                const int iy = y0 * STRIDE - PAD + P / IN_W;
+                const int ix = x0 * STRIDE - PAD + P % IN_W;
+                if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                    off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+            }
+            px_off[i] = off;
+        }
+    };
+    int w_off[NWU];
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+        const int u = i * NTHR + tid;
+        const int r = u % BN, th = u / BN;
+        w_off[i] = (th * CP + r) * 16;
+    }
+    uint4 rpx[NPXU];
+    auto dma_filters = [&](int s, int buf) {
+        const uint8_t* wp = ld_w + (size_t)s * w_stage_stride;
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            if (i * NTHR + wave * 64 < WU_TOTAL) {  // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + w_off[i]),
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * BUF_BYTES + W_BASE +
+                                                                                           (i * NTHR + wave * 64) * 16),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    auto load_pixels = [&](int s) {
+        const uint8_t* sp = ld_src + (size_t)s * NK * in_plane;
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (px_off[i] >= 0) v = *reinterpret_cast<const uint4*>(sp + px_off[i]);
+            rpx[i] = v;
+        }
+    };
+    auto store_pixels = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPXU; ++i) {
+            const int u = i * NTHR + tid;
+            if (u < PXU_TOTAL) {
+                const int kk = u / (2 * IN_PIX);
+                const int v = u % (2 * IN_PIX);
+                const int P = v >> 1, h = v & 1;
+                *reinterpret_cast<uint4*>(lds + buf * BUF_BYTES + kk * PIX_SLAB + (h * IN_PIX + P) * 16) = rpx[i];
+            }
+        }
+    };
+
+    int pb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int ty = p / TW, tx = p % TW;
+        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
+    }
+    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
+    const int nstages = a.cin / (16 * NK);
+
+    setup_loader(item);
+    dma_filters(0, 0);
+    load_pixels(0);
+    store_pixels(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+        // the item the MFMAs work on
+        const int cg = item % a.n_cgroups;
+        const int pt = item / a.n_cgroups;
+        const int b = pt / tiles_per_img;
+        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
+        const int next_item = item + slots;
+        const bool has_next = next_item < last;
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        ResRegs<MT, NT> rr;
+
+        for (int s = 0; s < nstages; ++s) {
+            const bool last_stage = (s + 1 == nstages);
+            const bool more = !last_stage || has_next;
+            if (!(a.dbg & 1)) {
+                if (!last_stage) {
+                    load_pixels(s + 1);
+                    dma_filters(s + 1, cur ^ 1);
+                } else if (has_next) {
+                    setup_loader(next_item);
+                    load_pixels(0);
+                    dma_filters(0, cur ^ 1);
+                }
+            }
+            if (last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+            const uint8_t* L = lds + cur * BUF_BYTES;
+            // fragments of step t+1 are requested before the MFMAs of step t issue (one full step of MFMA time to land)
+            constexpr int NSTEP = NK * KK2;
+            bf16x8 af[2][MT], bfr[2][NT];
+            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+                const int kk = t / KK2, tap = t % KK2;
+                const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    fa[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+            };
+            if (!(a.dbg & 2)) load_frags(0, af[0], bfr[0]);
+#pragma unroll
+            for (int t = 0; t < NSTEP; ++t) {
+                if (a.dbg & 2) break;
+                if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+                store_pixels(cur ^ 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage's filter DMA has landed
+                __syncthreads();
+            }
+            cur ^= 1;
+        }
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+        if (!has_next) break;
+        item = next_item;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// V4: persistent, ALL staging by LDS-DMA into a ring of NBUF stage buffers, counted vmcnt, raw s_barrier.
+//   * input pixels too go global -> LDS by DMA: lanes whose pixel falls outside the image (3x3 halo at the border,
+//     ragged tiles) read from a 64-byte page of zeros instead (the DMA source address is per lane);
+//   * stage g+NBUF-1 is issued before the MFMAs of stage g: NBUF-1 stages of DMA in flight per CU, which is what
+//     the latency-bound layers (1x1, small Cin) need (ablation in DESIGN.md: staging alone ran at one stage/us);
+//   * every wave issues the same number PW of 1-KiB DMA pieces per stage (the piece list is padded with dummy
+//     pieces that copy zeros into a scratch KiB), so "stage g+1 has landed" is one constant `s_waitcnt vmcnt(PW)`.
+__device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];  // zero-initialised by the loader
+
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int KK2 = KS * KS;
+    constexpr int NPIX = TH * TW;
+    constexpr int NT = NPIX / (WN * 32);
+    constexpr int MT = BN / (WM * 32);
+    constexpr int IN_H = (TH - 1) * STRIDE + KS;
+    constexpr int IN_W = (TW - 1) * STRIDE + KS;
+    constexpr int IN_PIX = IN_H * IN_W;
+    constexpr int PX_PIECES = (2 * IN_PIX + 63) / 64;       // 1-KiB DMA pieces per 16-channel pixel slab
+    constexpr int PIX_SLAB = PX_PIECES * 1024;
+    constexpr int W_PIECES = KK2 * 2 * BN * 16 / 1024;      // per 16-channel filter slab
+    constexpr int W_SLAB = W_PIECES * 1024;
+    constexpr int W_BASE = NK * PIX_SLAB;
+    constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
+    constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);
+    constexpr int PW = (NPIECE + 7) / 8;                    // pieces per wave per stage (dummy-padded)
+    constexpr int DUMMY_BASE = NBUF * BUF_BYTES;
+    constexpr int LDS_BYTES = NBUF * BUF_BYTES + 1024;
+    static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
+    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
+    static_assert((KK2 * 2 * BN * 16) % 1024 == 0, "filter slab is whole DMA pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS ring");
+    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int c = lane & 31, hh = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int per_xcd = (n_items + 7) >> 3;
+    const int first = xcd * per_xcd;
+    const int last = min(first + per_xcd, n_items);
+    int item = first + slot;
+    if (item >= last) return;
+
+    const size_t in_plane = (size_t)a.hin * a.win * 32;
+    const int CP = a.cout_pad;
+    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_zero_page);
+
+    // ---- loader: piece i of this wave is global piece q = i*8 + wave ------------------------------------------
+    // kind: pixel piece (kk, j) | filter piece (kk, j) | dummy.  Per lane: byte offset from the item's base, or -1.
+    int src_off[PW];
+    const uint8_t* ld_src = nullptr;
+    const uint8_t* ld_w = nullptr;
+    int ld_item = item, ld_s = 0;
+    bool ld_done = false;
+    auto setup_loader = [&](int it) {
+        const int cg = it % a.n_cgroups;
+        const int pt = it / a.n_cgroups;
+        const int b = pt / tiles_per_img;
+        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
+        ld_src = a.src + (size_t)b * (a.cin / 16) * in_plane;
+        ld_w = a.w + (size_t)cg * BN * 16;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int q = i * 8 + wave;
+            int off = -1;
+            if (q < NK * PX_PIECES) {
+                const int kk = q / PX_PIECES, j = q % PX_PIECES;
+                const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX]
+                const int h = u / IN_PIX, P = u % IN_PIX;
+                const int iy = y0 * STRIDE - PAD + P / IN_W;
+                const int ix = x0 * STRIDE - PAD + P % IN_W;
+                if (h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                    off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+            } else if (q < NPIECE) {
+                const int qq = q - NK * PX_PIECES;
+                const int u = qq * 64 + lane;          // unit inside the stage's filter image [kk][tap][half][BN]
+                const int r = u % BN, th = u / BN;
+                off = (th * CP + r) * 16;
+            }
+            src_off[i] = off;
+        }
+    };
+    auto issue_stage = [&](int buf) {  // DMA the loader's current stage into ring slot `buf`, then advance the loader
+        const uint8_t* sp = ld_src + (size_t)ld_s * NK * in_plane;
+        const uint8_t* wp = ld_w + (size_t)ld_s * w_stage_stride;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int q = i * 8 + wave;  // wave-uniform
+            const uint8_t* g;
+            int dst;
+            if (q < NK * PX_PIECES) {
+                const int kk = q / PX_PIECES, j = q % PX_PIECES;
+                g = sp + src_off[i];
+                dst = buf * BUF_BYTES + kk * PIX_SLAB + j * 1024;
+            } else if (q < NPIECE) {
+                g = wp + src_off[i];
+                dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
+            } else {
+                g = zero_page;
+                dst = DUMMY_BASE;
+            }
+            if (src_off[i] < 0) g = zero_page + (lane & 3) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
+        }
+        if (++ld_s == a.cin / (16 * NK)) {
+            ld_s = 0;
+            ld_item += slots;
+            if (ld_item < last)
+                setup_loader(ld_item);
+            else
+                ld_done = true;
+        }
+    };
+
+    int pb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int ty = p / TW, tx = p % TW;
+        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
+    }
+    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
+    const int nstages = a.cin / (16 * NK);
+
+    // ---- prologue: NBUF-1 stages in flight, stage 0 landed -----------------------------------------------------
+    setup_loader(item);
+    issue_stage(0);
+    if constexpr (NBUF == 3) {
+        if (!ld_done) {
+            issue_stage(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int cur = 0;  // ring slot of the stage the MFMAs read
+    while (true) {
+        const int cg = item % a.n_cgroups;
+        const int pt = item / a.n_cgroups;
+        const int b = pt / tiles_per_img;
+        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
+        const int next_item = item + slots;
+        const bool has_next = next_item < last;
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        ResRegs<MT, NT> rr;
+
+        for (int s = 0; s < nstages; ++s) {
+            const bool last_stage = (s + 1 == nstages);
+            // stage g+NBUF-1 -> the slot that was read during stage g-1 (every wave passed the barrier since)
+            bool issued = false;
+            if (!ld_done) {
+                int slot_ld = cur + (NBUF - 1);
+                if (slot_ld >= NBUF) slot_ld -= NBUF;
+                issue_stage(slot_ld);
+                issued = true;
+            }
+            constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
+            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+
+            const uint8_t* L = lds + cur * BUF_BYTES;
+            constexpr int NSTEP = NK * KK2;
+            bf16x8 af[2][MT], bfr[2][NT];
+            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+                const int kk = t / KK2, tap = t % KK2;
+                const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    fa[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+            };
+            load_frags(0, af[0], bfr[0]);
+#pragma unroll
+            for (int t = 0; t < NSTEP; ++t) {
+                if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // stage g+1 must have landed before anyone reads it: everything but the stage(s) issued after it
+            if (!(last_stage && !has_next)) {
+                if constexpr (NBUF == 3) {
+                    if (issued)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (++cur == NBUF) cur = 0;
+        }
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4)>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+        if (!has_next) break;
+        item = next_item;
+    }
+}
+
+template <int KS, int STRIDE, int BN, int TH, int TW, int NK>
+constexpr int ring_depth() {
+    constexpr int in_pix = ((TH - 1) * STRIDE + KS) * ((TW - 1) * STRIDE + KS);
+    constexpr int buf = NK * (((2 * in_pix + 63) / 64) * 1024 + KS * KS * 2 * BN * 16);
+    return (3 * buf + 1024 <= 160 * 1024) ? 3 : 2;
+}
+
+// AY_CONV_MODE: 1 = V1 (4 waves, register staging), 2 = V2 (8 waves, DMA filters), 3 = V3 persistent,
+// 4 = V4 persistent all-DMA ring (default)
+static int conv_mode() {
+    static const int m = getenv("AY_CONV_MODE") ? atoi(getenv("AY_CONV_MODE")) : 4;
+    return m;
+}
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n < 8) n = 256;
+        n -= n % 8;
+    }
+    return n;
 }
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
@@ -467,6 +983,8 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     a.tiles_y = (d->hout + TH - 1) / TH;
     a.n_cgroups = d->cout_pad / BN;
     a.leaky = d->leaky;
+    static const int dbg = getenv("AY_DBG") ? atoi(getenv("AY_DBG")) : 0;
+    a.dbg = dbg;
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);
@@ -475,7 +993,27 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     dim3 grid((unsigned)nblk), block(V2 ? 512 : 256);
     if constexpr (V2) {
         static_assert(!OUT_F32 || !V2, "V2 is instantiated for bf16 outputs only");
-        if (residual)
+        if (conv_mode() >= 4) {  // persistent all-DMA ring
+            const int per_xcd = (int)((nblk + 7) / 8);
+            const int cu_slots = num_cus() / 8;
+            dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
+            constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
+            if (residual)
+                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
+            else
+                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
+        } else if constexpr (TH * TW > 256) {
+            set_error("16x32 tile exists for the ring kernel only");
+            return AY_ERR_ARG;
+        } else if (conv_mode() == 3) {  // persistent: one workgroup per CU, items dealt per XCD
+            const int per_xcd = (int)((nblk + 7) / 8);
+            const int cu_slots = num_cus() / 8;
+            dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
+            if (residual)
+                hipLaunchKernelGGL((conv_bf16_persist_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true>), pgrid, block, 0, st, a, (int)nblk);
+            else
+                hipLaunchKernelGGL((conv_bf16_persist_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false>), pgrid, block, 0, st, a, (int)nblk);
+        } else if (residual)
             hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
@@ -509,7 +1047,10 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     const int cp = d->cout_pad;
     if (d->ksize == 3 && d->stride == 1) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
-        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;  // A/B switch for benchmarking
+        const int v1 = conv_mode() == 1;
+        static const int tile16 = getenv("AY_TILE16") ? atoi(getenv("AY_TILE16")) : 1;
+        if (cp % 128 == 0 && !v1 && tile16 && conv_mode() >= 4 && d->hout >= 16)
+            return launch<3, 1, 128, 2, 4, 16, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0 && !v1) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0 && !v1) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<3, 1, 128, 2, 2, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
@@ -518,7 +1059,7 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     }
     if (d->ksize == 3 && d->stride == 2) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
-        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;
+        const int v1 = conv_mode() == 1;
         if (cp % 128 == 0 && !v1) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0 && !v1) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<3, 2, 128, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
@@ -531,7 +1072,7 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
             return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
         }
-        static const int v1 = getenv("AY_CONV_V1") ? atoi(getenv("AY_CONV_V1")) : 0;
+        const int v1 = conv_mode() == 1;
         if (cp % 128 == 0 && !v1) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0 && !v1) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<1, 1, 128, 2, 2, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);

@@ -1,0 +1,31 @@
+"""Per-layer conv timings of the last bench step from a rocprofv3 --kernel-trace CSV.
+usage: python scripts/layer_times.py gpurun_out/profN [classes]"""
+import csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amyloid_yolo_paper_amd import cfg_gen
+from amyloid_yolo_paper_amd.models import Darknet
+
+d = sys.argv[1]
+f = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "stem_conv" in r["Kernel_Name"]]
+seq = rows[idx[-1]:]
+m = Darknet(cfg_gen.write_cfg(int(sys.argv[2]) if len(sys.argv) > 2 else 3, "/tmp/cfgt"))
+convs = [(i, e) for i, e in enumerate(m._graph) if e["type"] == "convolutional"]
+ci, tot, groups = 0, 0.0, {}
+for r in seq:
+    n = r["Kernel_Name"]
+    dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "conv_bf16" in n or "stem" in n:
+        i, e = convs[ci]; ci += 1
+        S = 1024 >> e["log2_down"]
+        fl = 2 * 64 * S * S * e["cout"] * e["cin"] * e["k"] ** 2
+        key = f"{e['cin']:4d}->{e['cout']:4d} k{e['k']} s{e['stride']} @{S:4d} {'res' if e['fuse_into_shortcut'] else '   '}"
+        g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
+        tot += dur
+    else:
+        g = groups.setdefault(n[:60], [0, 0.0, 0.0]); g[0] += 1; g[1] += dur
+for k, (n, t, fl) in groups.items():
+    print(f"{k:62s} x{n:3d} {t:9.1f} us total {t/n:8.1f} us each {fl/t/1e6 if fl else 0:7.1f} TF/s")
+print("conv total us", round(tot, 1), " all kernels us", round(sum(g[1] for g in groups.values()), 1))
