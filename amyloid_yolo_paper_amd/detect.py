@@ -1,0 +1,75 @@
+"""``detect()``: the body of the reference's ``detect.py`` script as a function with the same flags
+(reference ``detect.py:30-105``; the matplotlib rendering and the paper's merge/CAA post-processing at ``:107-171`` are
+out of scope).  Returns ``(image paths, list of [n,7] tensors | None)`` with boxes rescaled to each
+image's original size."""
+import argparse
+import datetime
+import time
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader
+
+from .datasets import ImageFolder
+from .models import Darknet
+from .utils import load_classes, non_max_suppression, rescale_boxes
+
+
+def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_path="weights/yolov3.weights",
+           class_path=None, conf_thres=0.8, nms_thres=0.4, batch_size=1, n_cpu=0, img_size=416, precision="bf16",
+           rescale=True, verbose=True):
+    model = Darknet(model_def, img_size=img_size, precision=precision).to("cuda")
+    if weights_path.endswith(".weights"):
+        model.load_darknet_weights(weights_path)
+    else:
+        model.load_state_dict(torch.load(weights_path))
+    model.eval()
+    loader = DataLoader(ImageFolder(image_folder, img_size=img_size), batch_size=batch_size, shuffle=False, num_workers=n_cpu)
+    classes = load_classes(class_path) if class_path else None
+    paths, results = [], []
+    prev = time.time()
+    for batch_i, (img_paths, imgs) in enumerate(loader):
+        with torch.no_grad():
+            dets = non_max_suppression(model(imgs), conf_thres, nms_thres)
+        now = time.time()
+        if verbose:
+            print("\t+ Batch %d, Inference Time: %s" % (batch_i, datetime.timedelta(seconds=now - prev)))
+        prev = now
+        paths.extend(img_paths)
+        results.extend(dets)
+    if rescale:
+        for path, det in zip(paths, results):
+            if det is not None:
+                w, h = Image.open(path).size
+                rescale_boxes(det, img_size, (h, w))
+    return paths, results, classes
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--image_folder", type=str, default="data/samples")
+    ap.add_argument("--model_def", type=str, default="config/yolov3.cfg")
+    ap.add_argument("--weights_path", type=str, default="weights/yolov3.weights")
+    ap.add_argument("--class_path", type=str, default="data/coco.names")
+    ap.add_argument("--conf_thres", type=float, default=0.8)
+    ap.add_argument("--nms_thres", type=float, default=0.4)
+    ap.add_argument("--batch_size", type=int, default=1)
+    ap.add_argument("--n_cpu", type=int, default=0)
+    ap.add_argument("--img_size", type=int, default=416)
+    ap.add_argument("--checkpoint_model", type=str)
+    ap.add_argument("--precision", type=str, default="bf16")
+    opt = ap.parse_args(argv)
+    paths, results, classes = detect(opt.image_folder, opt.model_def, opt.weights_path, opt.class_path, opt.conf_thres,
+                                     opt.nms_thres, opt.batch_size, opt.n_cpu, opt.img_size, opt.precision)
+    for path, det in zip(paths, results):
+        print(f"Image: '{path}'")
+        if det is None:
+            continue
+        for x1, y1, x2, y2, conf, cls_conf, cls_pred in det.tolist():
+            name = classes[int(cls_pred)] if classes else int(cls_pred)
+            print(f"\t+ Label: {name}, Conf: {cls_conf:.5f}, box: ({x1:.1f}, {y1:.1f}, {x2:.1f}, {y2:.1f})")
+
+
+if __name__ == "__main__":
+    main()
