@@ -39,6 +39,18 @@ _SIGS = {
     "ay_nms_workspace_bytes": (_SZ, [_I, _I]),
     "ay_nms_filter": (_I, [_P, _I, _I, _I, _F, _P, _P, _SZ, _P]),
     "ay_nms_sort_merge": (_I, [_P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ay_bn_train_fwd_f32": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "ay_bn_train_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "ay_bias_grad_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ay_conv_dgrad_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
+    "ay_conv_wgrad_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "ay_add_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "ay_accumulate_f32": (_I, [_P, _P, _SZ, _P]),
+    "ay_copy_channels_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ay_slice_accumulate_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ay_yolo_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "ay_yolo_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
+    "ay_adam_flat": (_I, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _F, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

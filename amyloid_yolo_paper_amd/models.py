@@ -264,6 +264,14 @@ class Darknet(nn.Module):
         self._prep = prep
         return prep
 
+    def _unit(self, n, dev):
+        """cached (ones[n], zeros[n]) device vectors: identity scale/shift for raw convolutions"""
+        cache = self.__dict__.setdefault("_unit_cache", {})
+        key = (n, str(dev))
+        if key not in cache:
+            cache[key] = (torch.ones(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32))
+        return cache[key]
+
     # ------------------------------------------------------------------ forward
     def num_boxes(self, S):
         return sum(y.num_anchors * (S >> e["log2_down"]) ** 2 for y, e in
@@ -272,10 +280,17 @@ class Darknet(nn.Module):
     def forward(self, x, targets=None):
         """Reference semantics (``models.py:237-255``): returns the CPU tensor ``[B, N, 5+C]``; the device copy is
         kept as ``out._ay_device`` so ``non_max_suppression`` does not upload it again."""
-        if targets is not None or self.training:
-            raise NotImplementedError(
-                "training forward/backward on the HIP path is not built yet (SURVEY.md §8 row 'train step'); "
-                "call model.eval() for inference")
+        if targets is not None:
+            # training step (fp32 reference-precision path this round; see train_engine.py): loss carries the autograd
+            # node whose backward runs the HIP dgrad/wgrad/BN/loss kernels and fills every parameter's .grad
+            from .train_engine import TrainStep
+            loss, dev_out = TrainStep.apply(self, x, targets, *self.parameters())
+            return loss, dev_out.detach().cpu()
+        if self.training:
+            from .train_engine import train_forward
+            with torch.no_grad():
+                _, dev_out, _ = train_forward(self, x, None)
+            return dev_out.detach().cpu()
         dev_out = self.forward_device(x)
         out = dev_out.detach().cpu()
         self._gen = getattr(self, "_gen", 0) + 1

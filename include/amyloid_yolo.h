@@ -127,6 +127,45 @@ int ay_nms_merge(float* pred, int batch, int n_rows, int num_classes, float conf
                  int max_det, float* out_rows, int32_t* keep_idx, int32_t* count, int32_t* cand_count,
                  void* workspace, size_t workspace_bytes, ay_stream_t stream);
 
+/* ---- training step, fp32 reference-precision path (nchw f32) -------------------------------------- */
+
+/* Train-mode BatchNorm2d + LeakyReLU forward (models.py:43-45): batch statistics over (B,H,W), biased variance for the
+ * normalisation, running stats updated with PyTorch semantics running = (1-momentum)*running + momentum*batch
+ * (unbiased variance), momentum = 0.9 in the reference.  z = raw conv output, y = block output. */
+int ay_bn_train_fwd_f32(const float* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, int leaky, float* y, float* save_mean, float* save_invstd,
+                        int batch, int channels, int hw, ay_stream_t stream);
+/* its backward (autograd of the above): dy -> dz, dgamma, dbeta (written, not accumulated) */
+int ay_bn_train_bwd_f32(const float* dy, const float* y, const float* z, const float* gamma, const float* save_mean,
+                        const float* save_invstd, int leaky, float* dz, float* dgamma, float* dbeta, int batch,
+                        int channels, int hw, ay_stream_t stream);
+int ay_bias_grad_f32(const float* dz, float* dbias, int batch, int channels, int hw, ay_stream_t stream);
+/* autograd of nn.Conv2d (models.py:33-40): input gradient (optionally accumulated into dx) and weight gradient */
+int ay_conv_dgrad_f32(const ay_conv_desc* d, const float* dz, const float* w_oihw, float* dx, int accumulate,
+                      ay_stream_t stream);
+int ay_conv_wgrad_f32(const ay_conv_desc* d, const float* x, const float* dz, float* dw, ay_stream_t stream);
+/* shortcut add (models.py:246-248), gradient accumulation, route/upsample copy (models.py:86-96,244-245) and its backward */
+int ay_add_f32(const float* a, const float* b, float* out, size_t n, ay_stream_t stream);
+int ay_accumulate_f32(float* dst, const float* src, size_t n, ay_stream_t stream);
+int ay_copy_channels_f32(const float* src, float* out, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
+                         ay_stream_t stream);
+int ay_slice_accumulate_f32(const float* dout, float* dsrc, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
+                            ay_stream_t stream);
+/* YOLO layer loss (models.py:174-222) with build_targets (utils/utils.py:276-330) fused: target assignment
+ * (best-of-A anchor by wh-IoU, ignore threshold, last-writer-wins scatter in target order), the six loss terms and the
+ * gradient w.r.t. the raw head tensor [B][A*(5+C)][G][G].  sums_out (device, 16 floats): [0..3] sum sq err x,y,w,h @obj,
+ * [4] BCE conf @obj, [5] BCE conf @noobj, [6] BCE cls @obj, [7] n_obj, [8] n_noobj, [9] class hits, [10] sum conf @obj,
+ * [11] sum conf @noobj, [12] #conf>0.5, [13] #(iou>0.5 & detected), [14] #(iou>0.75 & detected).
+ * loss = (s0+s1+s2+s3)/n_obj + s4/n_obj + 100*s5/n_noobj + s6/(n_obj*C); dhead = grad_scale * dloss/dhead. */
+size_t ay_yolo_loss_workspace_bytes(int batch, int num_anchors, int num_classes, int grid);
+int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors,
+                         int num_classes, int grid, int img_dim, const float* anchors_wh /* host */, float ignore_thres,
+                         float grad_scale, float* dhead, float* sums_out, void* workspace, size_t workspace_bytes,
+                         ay_stream_t stream);
+/* torch.optim.Adam step (train.py:81,118) on one flat buffer; grads are multiplied by grad_scale first (1/world size) */
+int ay_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                 float beta2, float eps, int step, float grad_scale, ay_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

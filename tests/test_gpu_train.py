@@ -1,0 +1,224 @@
+"""GPU (-m gpu): the training step on the HIP path (fp32 reference-precision) against the reference's own training
+step (tests/golden/train_*.npz, produced by oracle/gen_golden.py from the imported reference) and the CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from amyloid_yolo_paper_amd import _lib, cfg_gen, parse_config, synth
+from amyloid_yolo_paper_amd._lib import check, ptr
+from amyloid_yolo_paper_amd.models import Darknet
+from oracle import boxes_oracle as bo
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max(initial=0.0) <= tol, (what, float(err.max()))
+
+
+def _model(C_, cfg_dir):
+    cfg = cfg_gen.write_cfg(C_, cfg_dir)
+    defs = parse_config.parse_model_config(cfg)
+    wpath = os.path.join(cfg_dir, f"synth_c{C_}.weights")
+    if not os.path.exists(wpath):
+        synth.write_darknet_weights(wpath, defs, synth.synth_params(defs, seed=7), seen=12345)
+    m = Darknet(cfg, precision="fp32").to("cuda")
+    m.load_darknet_weights(wpath)
+    return m
+
+
+@pytest.mark.parametrize("case", gc.TRAIN_CASES, ids=lambda c: c[0])
+def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
+    """loss within 1e-4, the 13 per-layer metrics within 2e-4, sampled gradients within 2e-3 of the layer's gradient
+    scale (fp32 sums over up to 10^5 terms in a different order), BN running statistics within 1e-4."""
+    name, C_, S, B, seed = case
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = _model(C_, tmp_cfg_dir)
+    m.train()
+    tg = torch.from_numpy(gc.train_targets(B, C_, S, seed))
+    x = torch.from_numpy(gc.model_inputs(S, B, 10))
+    loss, out = m(x, tg)
+    assert not out.is_cuda and out.shape == (B, m.num_boxes(S), 5 + C_)
+    # train-mode outputs: batch statistics over as few as B*G*G = 27..32 samples per channel divide a 1e-6 relative
+    # summation-order difference of the convolution by a small sigma: 1e-3 here, 1e-4 in the eval-mode parity tests
+    close(out.numpy(), z["out"], 1e-3, "train-mode outputs")
+    loss.backward()
+    close(loss.item(), z["loss"], 1e-4, "loss")
+    keys = list(z["metric_keys"])
+    got = np.array([[yl.metrics[k] for k in keys] for yl in m.yolo_layers])
+    close(got, z["metrics"], 2e-4, "metrics")
+    # Gradients.  The three linear heads (no LeakyReLU between them and the loss) must match to 2e-4 of the layer's
+    # gradient scale.  Below a LeakyReLU the comparison is inherently looser: a pre-activation within ~1e-5 of zero
+    # takes slope 1 on one side and 0.1 on the other, and a different fp32 summation order in the convolution flips
+    # the sign of a handful of such elements per step (17 of ~10^7 in this case, scripts/dbg_train.py lists them).
+    # Each flip changes dz at one element by up to 10x and spreads from there, so those layers are held to
+    # 3 % of the gradient scale element-wise and 3 % in relative L2; the kernels themselves are pinned tightly,
+    # one by one, in test_backward_kernels_vs_autograd below.
+    def check_grad(g, ref, tight, what):
+        g, ref = np.asarray(g, np.float64), np.asarray(ref, np.float64)
+        scale = max(np.abs(ref).max(), 1e-12)
+        if tight:
+            assert np.abs(g - ref).max() <= 2e-4 * scale, (what, float(np.abs(g - ref).max() / scale))
+        else:
+            assert np.abs(g - ref).max() <= 3e-2 * scale, (what, float(np.abs(g - ref).max() / scale))
+            assert np.linalg.norm(g - ref) <= 3e-2 * np.linalg.norm(ref), (what, float(np.linalg.norm(g - ref) / np.linalg.norm(ref)))
+
+    for li in (0, 1, 2, 42, 73, 80, 81, 93, 104, 105):
+        conv = m.module_list[li][0]
+        g = conv.weight.grad.cpu().numpy()
+        ref = z[f"gw{li}"]
+        if ref.shape != g.shape:
+            g = g.reshape(-1)[:: max(1, g.size // 65536)]
+        tight = li in (81, 93, 105)
+        check_grad(g, ref, tight, f"dW{li}")
+        if conv.bias is not None:
+            check_grad(conv.bias.grad.cpu().numpy(), z[f"gb{li}"], tight, f"db{li}")
+        else:
+            bn = m.module_list[li][1]
+            check_grad(bn.weight.grad.cpu().numpy(), z[f"ggamma{li}"], False, f"dgamma{li}")
+            check_grad(bn.bias.grad.cpu().numpy(), z[f"gbeta{li}"], False, f"dbeta{li}")
+            close(bn.running_mean.cpu().numpy(), z[f"rmean{li}"], 1e-4, "running_mean")
+            close(bn.running_var.cpu().numpy(), z[f"rvar{li}"], 1e-4, "running_var")
+            assert int(bn.num_batches_tracked) == 1
+
+
+def test_backward_kernels_vs_autograd():
+    """every backward kernel of the fp32 training path against torch-CPU autograd of the same op on random data"""
+    import torch.nn.functional as F
+    from amyloid_yolo_paper_amd._lib import ConvDesc
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(3)
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+
+    # --- train-mode BN + leaky, forward and backward
+    B, Cc, H = 3, 20, 7
+    zt = torch.randn(B, Cc, H, H, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm, rv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    dy = torch.randn(B, Cc, H, H, generator=g)
+    zr, gr, br = zt.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.leaky_relu(F.batch_norm(zr, rm_ref, rv_ref, gr, br, True, 0.9, 1e-5), 0.1)
+    yr.backward(dy)
+    zd, gd, bd, rmd, rvd, dyd = (t.to(dev) for t in (zt, gamma, beta, rm, rv, dy))
+    yd, mean, invstd = torch.empty_like(zd), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    check(L.ay_bn_train_fwd_f32(ptr(zd), ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), C.c_float(0.9), C.c_float(1e-5), 1, ptr(yd), ptr(mean),
+                                ptr(invstd), B, Cc, H * H, st))
+    assert rel(yd, yr.detach()) < 1e-5 and rel(rmd, rm_ref) < 1e-6 and rel(rvd, rv_ref) < 1e-6
+    dzd, dgd, dbd = torch.empty_like(zd), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    check(L.ay_bn_train_bwd_f32(ptr(dyd), ptr(yd), ptr(zd), ptr(gd), ptr(mean), ptr(invstd), 1, ptr(dzd), ptr(dgd), ptr(dbd), B, Cc, H * H, st))
+    assert rel(dzd, zr.grad) < 2e-5 and rel(dgd, gr.grad) < 1e-5 and rel(dbd, br.grad) < 1e-5
+
+    # --- conv dgrad / wgrad / bias grad: 3x3 s1, 3x3 s2 (odd size), 1x1
+    for cin, cout, k, s, H in ((5, 7, 3, 1, 9), (6, 4, 3, 2, 11), (8, 3, 1, 1, 6), (4, 6, 3, 2, 8)):
+        x = torch.randn(2, cin, H, H, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, s, (k - 1) // 2)
+        dz = torch.randn(yr.shape, generator=g)
+        yr.backward(dz)
+        Ho = yr.shape[2]
+        d = ConvDesc(2, cin, cout, H, H, Ho, Ho, k, s, 0, 0, cout)
+        xd, wd, dzd = x.to(dev), w.to(dev), dz.to(dev)
+        dx = torch.full_like(xd, 1.0)
+        check(L.ay_conv_dgrad_f32(C.byref(d), ptr(dzd), ptr(wd), ptr(dx), 1, st))       # accumulate onto ones
+        assert rel(dx - 1.0, xr.grad) < 1e-5, (cin, cout, k, s)
+        check(L.ay_conv_dgrad_f32(C.byref(d), ptr(dzd), ptr(wd), ptr(dx), 0, st))
+        assert rel(dx, xr.grad) < 1e-5
+        dw = torch.empty_like(wd)
+        check(L.ay_conv_wgrad_f32(C.byref(d), ptr(xd), ptr(dzd), ptr(dw), st))
+        assert rel(dw, wr.grad) < 1e-5, (cin, cout, k, s)
+        db = torch.empty(cout, device=dev)
+        check(L.ay_bias_grad_f32(ptr(dzd), ptr(db), 2, cout, Ho * Ho, st))
+        assert rel(db, dz.sum((0, 2, 3))) < 1e-5
+
+    # --- route / upsample copy and its backward, shortcut add, accumulate
+    a = torch.randn(2, 4, 3, 3, generator=g)
+    b_ = torch.randn(2, 5, 6, 6, generator=g)
+    ar, brq = a.clone().requires_grad_(True), b_.clone().requires_grad_(True)
+    cat = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), brq], 1)
+    dcat = torch.randn(cat.shape, generator=g)
+    cat.backward(dcat)
+    ad, bd2, od = a.to(dev), b_.to(dev), torch.empty(2, 9, 6, 6, device=dev)
+    check(L.ay_copy_channels_f32(ptr(ad), ptr(od), 2, 4, 9, 0, 6, 6, 1, st))
+    check(L.ay_copy_channels_f32(ptr(bd2), ptr(od), 2, 5, 9, 4, 6, 6, 0, st))
+    assert torch.equal(od.cpu(), cat.detach())
+    dcd, da, db2 = dcat.to(dev), torch.zeros_like(ad), torch.zeros_like(bd2)
+    check(L.ay_slice_accumulate_f32(ptr(dcd), ptr(da), 2, 4, 9, 0, 6, 6, 1, st))
+    check(L.ay_slice_accumulate_f32(ptr(dcd), ptr(db2), 2, 5, 9, 4, 6, 6, 0, st))
+    assert rel(da, ar.grad) < 1e-6 and torch.equal(db2.cpu(), brq.grad)
+    s1, s2 = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    s1d, s2d, so = s1.to(dev), s2.to(dev), torch.empty(1000, device=dev)
+    check(L.ay_add_f32(ptr(s1d), ptr(s2d), ptr(so), 1000, st))
+    check(L.ay_accumulate_f32(ptr(s1d), ptr(s2d), 1000, st))
+    assert torch.equal(so.cpu(), s1 + s2) and torch.equal(s1d.cpu(), s1 + s2)
+
+
+def test_yolo_loss_kernel_duplicates_and_grad():
+    """loss kernel alone vs the oracle's build_targets + torch autograd, with duplicate (b, anchor, cell) targets
+    (last writer wins, multi-hot tcls) and targets in every image."""
+    import torch.nn.functional as F
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    B, A, Cc, G, S = 3, 3, 3, 8, 64
+    rng = np.random.Generator(np.random.PCG64(5))
+    head = torch.from_numpy(rng.normal(0, 1, (B, A * (5 + Cc), G, G)).astype(np.float32))
+    tg = np.array([[0, 1, .31, .33, .3, .4], [0, 2, .32, .34, .31, .39], [1, 0, .7, .2, .1, .15], [1, 2, .71, .21, .6, .7],
+                   [2, 1, .5, .5, .9, .9], [2, 1, .12, .88, .05, .07], [0, 0, .9, .9, .2, .2]], np.float32)
+    anchors = [(10, 13), (16, 30), (33, 23)]
+    # oracle: decode + build_targets (NumPy) + the six loss terms with torch autograd on the raw head
+    h = head.clone().requires_grad_(True)
+    p = h.view(B, A, 5 + Cc, G, G).permute(0, 1, 3, 4, 2)
+    sx, sy, w, hh = torch.sigmoid(p[..., 0]), torch.sigmoid(p[..., 1]), p[..., 2], p[..., 3]
+    conf, cls = torch.sigmoid(p[..., 4]), torch.sigmoid(p[..., 5:])
+    _, boxes, aux = bo.decode(head.numpy(), anchors, Cc, S)
+    bt = bo.build_targets(boxes, aux["cls"], tg, aux["scaled_anchors"], 0.5)
+    iou_scores, class_mask, obj, noobj, tx, ty, tw, th, tcls, tconf = [torch.from_numpy(np.ascontiguousarray(v)) for v in bt]
+    loss = (F.mse_loss(sx[obj], tx[obj]) + F.mse_loss(sy[obj], ty[obj]) + F.mse_loss(w[obj], tw[obj]) + F.mse_loss(hh[obj], th[obj])
+            + F.binary_cross_entropy(conf[obj], tconf[obj]) + 100 * F.binary_cross_entropy(conf[noobj], tconf[noobj])
+            + F.binary_cross_entropy(cls[obj], tcls[obj]))
+    loss.backward()
+    hd, td = head.to(dev), torch.from_numpy(tg).to(dev)
+    dhead = torch.empty_like(hd)
+    sums = torch.empty(16, device=dev)
+    ws = torch.empty(L.ay_yolo_loss_workspace_bytes(B, A, Cc, G), device=dev, dtype=torch.uint8)
+    an = (C.c_float * 6)(*[float(v) for a in anchors for v in a])
+    check(L.ay_yolo_loss_fwd_bwd(ptr(hd), ptr(td), tg.shape[0], B, A, Cc, G, S, an, C.c_float(0.5), C.c_float(1.0), ptr(dhead), ptr(sums),
+                                 ptr(ws), ws.numel(), _lib.stream_ptr()))
+    s = sums.cpu().numpy().astype(np.float64)
+    got = (s[0] + s[1] + s[2] + s[3]) / s[7] + s[4] / s[7] + 100 * s[5] / s[8] + s[6] / (s[7] * Cc)
+    assert int(s[7]) == int(obj.sum()) and int(s[8]) == int(noobj.sum())           # same masks (integer-exact)
+    assert abs(got - loss.item()) <= 1e-5 * abs(loss.item())
+    g = h.grad.numpy()
+    assert np.abs(dhead.cpu().numpy() - g).max() <= 1e-5 * np.abs(g).max() + 1e-8
+    assert int(s[9]) == int(class_mask[obj].sum())
+
+
+def test_adam_flat_matches_torch():
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(10007, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref])
+    p = p0.to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = torch.randn(10007, generator=g)
+        p_ref.grad = gr.clone()
+        opt.step()
+        grd = gr.to(dev)
+        check(L.ay_adam_flat(ptr(p), ptr(grd), ptr(m), ptr(v), p.numel(), C.c_float(1e-3), C.c_float(0.9), C.c_float(0.999),
+                             C.c_float(1e-8), step, C.c_float(1.0), _lib.stream_ptr()))
+    assert (p.cpu() - p_ref.detach()).abs().max() <= 1e-6
