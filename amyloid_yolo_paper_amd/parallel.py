@@ -1,0 +1,102 @@
+"""Data parallelism over tiles: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" for the CPU tests).  The reference has no multi-GPU code at all: this is new.
+
+* Inference shards by image: `shard_indices` deals tile indices round-robin to ranks; no data-path collective.
+* Training is synchronous data parallel with ONE exchange per optimiser step: every parameter's `.grad` is a view into
+  one flat fp32 buffer (61.5 M parameters -> 246 MB), all-reduced in a few large buckets issued in reverse layer order
+  (deepest layers' gradients are final first), then scaled by 1/world.  xGMI is point-to-point (7 links per GPU), so
+  few large messages beat many small ones; BatchNorm stays per replica, like the reference's plain `nn.BatchNorm2d`
+  (`models.py:43`), and rank 0's running statistics are the ones checkpointed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items, rank, world):
+    """round-robin shard of tile indices: rank r takes r, r+world, ... (every tile exactly once, sizes differ by <= 1)"""
+    return list(range(rank, n_items, world))
+
+
+class FlatGradReducer:
+    """All parameters' gradients as views of one flat buffer + bucketed all-reduce.
+
+    usage:  red = FlatGradReducer(model.parameters(), n_buckets=4)     # once; sets p.grad (zeros)
+            loss.backward() ...                                         # autograd accumulates in place into the views
+            red.all_reduce()                                            # before optimizer.step() on a step boundary
+            optimizer.zero_grad(set_to_none=False)  or  red.zero()      # keep the views
+    """
+
+    def __init__(self, params, n_buckets=4, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self.offsets.append((off, n))
+            off += n
+        # buckets: contiguous ranges of the flat buffer, reduced from the END (deep layers) to the start
+        n_buckets = max(1, min(n_buckets, len(self.params)))
+        target = (total + n_buckets - 1) // n_buckets
+        self.buckets, start, acc = [], 0, 0
+        for (o, n) in self.offsets:
+            acc += n
+            if acc >= target:
+                self.buckets.append((start, o + n))
+                start, acc = o + n, 0
+        if start < total:
+            self.buckets.append((start, total))
+
+    def views_intact(self):
+        return all(p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * o for p, (o, _) in zip(self.params, self.offsets))
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, average=True):
+        """sum over ranks (bucketed, async, reverse order), then 1/world; returns the number of bytes exchanged per rank"""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return 0
+        assert self.views_intact(), "parameter .grad no longer aliases the flat buffer (zero_grad(set_to_none=True)?)"
+        world = dist.get_world_size(self.group)
+        handles = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for (a, b) in reversed(self.buckets)]
+        for h in handles:
+            h.wait()
+        if average:
+            self.flat.mul_(1.0 / world)
+        return self.flat.numel() * 4
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """make every replica start from rank `src`'s weights and BN statistics"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
