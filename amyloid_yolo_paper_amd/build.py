@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libamyloid_yolo_hip.so")
-SOURCES = ["ay_layout.hip", "ay_conv_bf16.hip", "ay_conv_f32.hip", "ay_yolo.hip", "ay_nms.hip", "ay_train_f32.hip"]
+SOURCES = ["ay_layout.hip", "ay_conv_bf16.hip", "ay_conv_f32.hip", "ay_yolo.hip", "ay_nms.hip", "ay_train_f32.hip", "ay_stem_fused.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -27,7 +27,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "ay_common.h"), os.path.join(HERE, "..", "include", "amyloid_yolo.h")]
+    headers = [os.path.join(CSRC, "ay_common.h"), os.path.join(CSRC, "ay_conv_common.h"), os.path.join(HERE, "..", "include", "amyloid_yolo.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

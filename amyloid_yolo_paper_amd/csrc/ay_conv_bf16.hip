@@ -18,147 +18,9 @@
 //   LDS filters  [kstep][tap][half][BN][8 bf16]
 #include <stdlib.h>
 
-#include "ay_common.h"
+#include "ay_conv_common.h"
 
 namespace ay {
-
-struct ConvArgs {
-    const uint8_t* src;
-    const uint8_t* w;
-    const float* scale;
-    const float* shift;
-    const uint8_t* residual;
-    uint8_t* out;
-    int batch, cin, cout_pad, hin, win, hout, wout;
-    int tiles_x, tiles_y, n_cgroups;
-    int leaky;
-    int dbg;  // timing experiments only (AY_DBG): 1 = no staging in the stage loop, 2 = no MFMA phase
-};
-
-// ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
-// C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-// A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
-// v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
-// residual operand of one wave tile, in the accumulator's own layout: [m][n][quad pair][quad] x 8 bytes
-template <int MT, int NT>
-struct ResRegs {
-    uint2 r[MT][NT][2][2];
-};
-
-template <int BN, int MT, int NT, int TW, bool HAS_RES>
-__device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT, NT>& rr, int b, int cg, int wm, int wn, int c,
-                                                  int hh, int y0, int x0) {
-    if constexpr (HAS_RES) {
-        const int CP = a.cout_pad;
-        const size_t out_plane_px = (size_t)a.hout * a.wout;
-        const int cbase = cg * BN + wm * MT * 32;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int p = (wn * NT + n) * 32 + c;
-            const int oy = y0 + p / TW, ox = x0 + p % TW;
-            const bool ok = (oy < a.hout) && (ox < a.wout);
-            const size_t pix = (size_t)oy * a.wout + ox;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    const int ch0 = cbase + m * 32 + qp * 16;
-                    const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
-                    uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
-                    if (ok) {
-                        const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                        v0 = *reinterpret_cast<const uint2*>(rp);
-                        v1 = *reinterpret_cast<const uint2*>(rp + 16);
-                    }
-                    rr.r[m][n][qp][0] = v0;
-                    rr.r[m][n][qp][1] = v1;
-                }
-        }
-    }
-}
-
-template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
-                                              int wm, int wn, int c, int hh, int y0, int x0) {
-    const int CP = a.cout_pad;
-    const size_t out_plane_px = (size_t)a.hout * a.wout;
-    const int cbase = cg * BN + wm * MT * 32;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int p = (wn * NT + n) * 32 + c;
-        const int oy = y0 + p / TW, ox = x0 + p % TW;
-        const bool ok = (oy < a.hout) && (ox < a.wout);
-        const size_t pix = (size_t)oy * a.wout + ox;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
-                const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
-                float v[4], w[4];
-                {
-                    const float4 s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
-                    const float4 t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
-                    const float4 s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
-                    const float4 t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
-                    const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
-                    const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x0v = acc[m][n][(2 * qp) * 4 + j] * ss0[j] + tt0[j];
-                        float x1v = acc[m][n][(2 * qp + 1) * 4 + j] * ss1[j] + tt1[j];
-                        if (a.leaky) {
-                            x0v = x0v > 0.f ? x0v : 0.1f * x0v;
-                            x1v = x1v > 0.f ? x1v : 0.1f * x1v;
-                        }
-                        v[j] = x0v;
-                        w[j] = x1v;
-                    }
-                }
-                const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
-                if constexpr (OUT_F32) {
-                    // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
-                    if (ok) {
-                        float* o = reinterpret_cast<float*>(a.out) + (plane * out_plane_px + pix) * 16;
-                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w[0], w[1], w[2], w[3]);
-                    }
-                } else {
-                    const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
-                    if constexpr (HAS_RES) {
-                        // residual (prefetched in the accumulator's own layout) added in fp32 before the single rounding
-                        uint2 r0v, r1v;
-                        if constexpr (RES_INLINE) {  // large wave tiles: no room to hold the whole residual in registers
-                            r0v = r1v = make_uint2(0, 0);
-                            if (ok) {
-                                const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                                r0v = *reinterpret_cast<const uint2*>(rp);
-                                r1v = *reinterpret_cast<const uint2*>(rp + 16);
-                            }
-                        } else {
-                            r0v = rr.r[m][n][qp][0];
-                            r1v = rr.r[m][n][qp][1];
-                        }
-                        v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
-                        v[1] += bf2f((uint16_t)(r0v.x >> 16));
-                        v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
-                        v[3] += bf2f((uint16_t)(r0v.y >> 16));
-                        w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
-                        w[1] += bf2f((uint16_t)(r1v.x >> 16));
-                        w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
-                        w[3] += bf2f((uint16_t)(r1v.y >> 16));
-                    }
-                    {
-                        unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
-                        unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
-                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
-                        if (ok) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                    }
-                }
-            }
-        }
-    }
-}
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
@@ -950,7 +812,7 @@ static int conv_mode() {
     static const int m = getenv("AY_CONV_MODE") ? atoi(getenv("AY_CONV_MODE")) : 4;
     return m;
 }
-static int num_cus() {
+int conv_num_cus() {
     static int n = 0;
     if (!n) {
         int dev = 0;
@@ -995,7 +857,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         static_assert(!OUT_F32 || !V2, "V2 is instantiated for bf16 outputs only");
         if (conv_mode() >= 4) {  // persistent all-DMA ring
             const int per_xcd = (int)((nblk + 7) / 8);
-            const int cu_slots = num_cus() / 8;
+            const int cu_slots = conv_num_cus() / 8;
             dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
             constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
             if (residual)
@@ -1007,7 +869,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             return AY_ERR_ARG;
         } else if (conv_mode() == 3) {  // persistent: one workgroup per CU, items dealt per XCD
             const int per_xcd = (int)((nblk + 7) / 8);
-            const int cu_slots = num_cus() / 8;
+            const int cu_slots = conv_num_cus() / 8;
             dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
             if (residual)
                 hipLaunchKernelGGL((conv_bf16_persist_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true>), pgrid, block, 0, st, a, (int)nblk);

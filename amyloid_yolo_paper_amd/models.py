@@ -115,6 +115,7 @@ class Darknet(nn.Module):
         self._act_bufs = {}      # (precision, B, S) -> per-layer device tensors
         self.keep_layer_outputs = False
         self.layer_outputs = None
+        self.stem_mode = "fused_bf16"   # "fp32": separate fp32 stem kernel (layer 0 output materialised)
 
     # ------------------------------------------------------------------ graph analysis
     def _analyse(self):
@@ -166,6 +167,11 @@ class Darknet(nn.Module):
             e["fuse_into_shortcut"] = (e["type"] == "convolutional" and users[i] == [i + 1] and i + 1 < n
                                        and info[i + 1]["type"] == "shortcut" and info[i + 1]["a"] == i
                                        and info[i + 1]["b"] != i)
+        # layer 0 (3->32 3x3 s1) + layer 1 (32->64 3x3 s2): fused stem kernel, layer 0's output never materialised
+        self._fuse_stem = (n > 1 and info[0]["type"] == "convolutional" and info[1]["type"] == "convolutional"
+                           and (info[0]["cin"], info[0]["cout"], info[0]["k"], info[0]["stride"], info[0]["bn"]) == (3, 32, 3, 1, True)
+                           and (info[1]["cout"], info[1]["k"], info[1]["stride"], info[1]["bn"]) == (64, 3, 2, True)
+                           and users[0] == [1] and not info[1]["fuse_into_shortcut"])
         self._users = users
         return info
 
@@ -253,6 +259,10 @@ class Darknet(nn.Module):
                 check(L.ay_fold_bn(None, None, None, None, ptr(bias), C.c_float(0.0), ptr(scale), ptr(shift), cout, cpad, st),
                       "ay_fold_bn")
             entry = dict(scale=scale, shift=shift, cpad=cpad, w=w, stem=first and self.precision == "bf16")
+            if entry["stem"]:  # [32][32] bf16 A-operand image of the stem filters for the fused stem kernel (k 27..31 = 0)
+                w0 = torch.zeros(32, 32, device=device, dtype=torch.float32)
+                w0[:, :27] = w.reshape(32, 27)
+                entry["w0_bf16"] = w0.to(torch.bfloat16).contiguous()
             if self.precision == "bf16" and not entry["stem"]:
                 assert e["cin"] % 16 == 0, f"layer {i}: cin {e['cin']} is not a multiple of 16"
                 nbytes = L.ay_packed_weight_bytes(cpad, e["cin"], e["k"])
@@ -299,8 +309,9 @@ class Darknet(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_device(self, x):
-        """x [B,3,S,S] float32 (any device) -> device tensor [B, N, 5+C] (valid until the next forward)."""
+    def forward_device(self, x, out_slot=0):
+        """x [B,3,S,S] float32 (any device) -> device tensor [B, N, 5+C] (valid until the next forward into the same
+        ``out_slot``; two slots let NMS of batch i run on a side stream while batch i+1 computes)."""
         if not torch.cuda.is_available():
             raise _lib.AyError("no HIP device: the amyloid-yolo hot path has no CPU fallback")
         L = _lib.lib()
@@ -316,9 +327,10 @@ class Darknet(nn.Module):
         bufs = self._act_bufs.setdefault(key, {})
         C_ = self.yolo_layers[0].num_classes
         N = self.num_boxes(S)
-        if "out" not in bufs:
-            bufs["out"] = torch.empty(B, N, 5 + C_, device=dev, dtype=torch.float32)
-        out = bufs["out"]
+        okey = ("out", out_slot)
+        if okey not in bufs:
+            bufs[okey] = torch.empty(B, N, 5 + C_, device=dev, dtype=torch.float32)
+        out = bufs[okey]
 
         def size_of(i):
             return S >> self._graph[i]["log2_down"] if i >= 0 else S
@@ -369,6 +381,17 @@ class Darknet(nn.Module):
                 d = ConvDesc(B, e["cin"], e["cout"], hin, hin, hout, hout, e["k"], e["stride"], int(e["leaky"]),
                              int(bf16 and is_head), p["cpad"])
                 tgt = i + 1 if fuse else i
+                if bf16 and i == 0 and self._fuse_stem and self.stem_mode == "fused_bf16":
+                    val[i] = ("fused", None)
+                    continue
+                if bf16 and i == 1 and val.get(0, (None,))[0] == "fused":
+                    p0 = prep["layers"][0]
+                    o = buf(tgt)
+                    check(L.ay_stem_s2_fused_fwd(ptr(x), ptr(p0["w0_bf16"]), ptr(p0["scale"]), ptr(p0["shift"]), int(self._graph[0]["leaky"]),
+                                                 ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]), int(e["leaky"]), ptr(o), B, S, S, st),
+                          "ay_stem_s2_fused_fwd")
+                    val[i] = ("t", o)
+                    continue
                 if bf16:
                     if p["stem"]:
                         o = buf(tgt)

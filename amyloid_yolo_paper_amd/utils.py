@@ -106,9 +106,9 @@ class NmsResult(list):
 _ws_cache = {}
 
 
-def nms_workspace(B, N, dev):
+def nms_workspace(B, N, dev, slot=0):
     nbytes = _lib.lib().ay_nms_workspace_bytes(B, N)
-    key = str(dev)
+    key = (str(dev), slot)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), device=dev, dtype=torch.uint8)
@@ -116,8 +116,8 @@ def nms_workspace(B, N, dev):
     return ws
 
 
-def nms_device(pred_dev, conf_thres, nms_thres, max_det):
-    """Raw fused device call (no host sync): pred_dev [B,N,5+C] float32 CUDA tensor, corners IN PLACE.
+def nms_device(pred_dev, conf_thres, nms_thres, max_det, slot=0):
+    """Raw fused device call (no host sync) on the current stream: pred_dev [B,N,5+C] float32 CUDA tensor, corners IN PLACE.
     Returns (rows [B,max_det,7], keep [B,max_det] i32, count [B] i32, cand_count [B] i32) device tensors;
     ``count[b] > max_det`` means image b had more cluster heads than the buffers hold."""
     L = _lib.lib()
@@ -127,7 +127,7 @@ def nms_device(pred_dev, conf_thres, nms_thres, max_det):
     keep = torch.empty(B, max_det, device=dev, dtype=torch.int32)
     count = torch.empty(B, device=dev, dtype=torch.int32)
     cand = torch.empty(B, device=dev, dtype=torch.int32)
-    ws = nms_workspace(B, N, dev)
+    ws = nms_workspace(B, N, dev, slot)
     check(L.ay_nms_merge(ptr(pred_dev), B, N, K - 5, C.c_float(conf_thres), C.c_float(nms_thres), max_det, ptr(rows), ptr(keep),
                          ptr(count), ptr(cand), ptr(ws), ws.numel(), _lib.stream_ptr()), "ay_nms_merge")
     return rows, keep, count, cand

@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--unique_tiles", type=int, default=16, help="distinct synthetic tiles (repeated to fill the batch)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_tiles", type=int, default=4)
+    ap.add_argument("--serial_nms", action="store_true", help="run merge-NMS on the main stream (no overlap with the next batch)")
     ap.add_argument("--no_layer_events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--traffic_json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="optional {kernel family: HBM bytes per launch} from a rocprofv3 --pmc pass")
@@ -99,9 +100,30 @@ def main():
     fam_flops = sum(conv_flops(model._graph[i], a.batch, a.size) for i in fam)
     total_flops = sum(conv_flops(e, a.batch, a.size) for e in model._graph if e["type"] == "convolutional")
 
+    # The decode output is double-buffered and merge-NMS of batch i runs on a side stream while the convolutions of
+    # batch i+1 run on the main stream (NMS keeps 64 of 256 CUs busy with one wave each; it hides completely).
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    slot_free = [None, None]
+    counter = [0]
+
     def step():
-        out = model.forward_device(x)
-        return nms_device(out, a.conf_thres, a.nms_thres, a.max_det)
+        slot = counter[0] & 1
+        counter[0] += 1
+        if slot_free[slot] is not None:
+            main.wait_event(slot_free[slot])          # NMS that read this output slot two steps ago is done
+        out = model.forward_device(x, out_slot=slot)
+        if a.serial_nms:
+            return nms_device(out, a.conf_thres, a.nms_thres, a.max_det, slot)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            res = nms_device(out, a.conf_thres, a.nms_thres, a.max_det, slot)
+            done = torch.cuda.Event()
+            done.record(side)
+        slot_free[slot] = done
+        return res
 
     for _ in range(a.warmup):
         res = step()

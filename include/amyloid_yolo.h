@@ -67,6 +67,14 @@ int ay_fold_bn(const float* gamma, const float* beta, const float* mean, const f
 int ay_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
                      void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream);
 
+/* Layer 0 + layer 1 of the Darknet-53 stem fused (3x3 s1 3->32, then 3x3 s2 32->64, each with BN affine + leaky): the
+ * 32-channel full-resolution intermediate stays in LDS.  stem_w_bf16: [32][32] bf16, k = ci*9+kh*3+kw (27..31 zero);
+ * w1_packed: ay_pack_conv_weights_bf16 of the 64x32x3x3 filters (cout_pad 64); out: blocked bf16 [B][4][H/2][W/2][16].
+ * The image and the stem filters enter the MFMA as bf16 (fp32 accumulate). */
+int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const float* scale0, const float* shift0, int leaky0,
+                         const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
+                         int batch, int h, int w, ay_stream_t stream);
+
 /* 3x3 (stride 1|2) and 1x1 convolution, blocked bf16 in, MFMA 32x32x16 bf16, fp32 accumulate,
  * fused scale/shift + leaky + residual epilogue; `residual` (blocked bf16, output shape) may be NULL. */
 int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,

@@ -9,8 +9,9 @@ what the reference dispatches to (SURVEY.md §8c "third-party arithmetic").
 ``mode="bf16"`` emulates the numeric contract of the HIP bf16 path so layer
 outputs can be compared tightly: conv operands rounded to bfloat16, fp32
 accumulation, fp32 BN-affine + LeakyReLU (+ residual) epilogue, ONE rounding to
-bfloat16 per stored activation; the stem (fp32 image in) and the three linear
-heads (fp32 out) are not rounded.
+bfloat16 per stored activation; the three linear heads (fp32 out) are not rounded.
+The stem takes the fp32 image: with ``stem_bf16=True`` (the fused stem kernel, default) image and stem filters are
+rounded to bfloat16 like every other operand, with ``stem_bf16=False`` (the separate fp32 stem kernel) they are not.
 """
 import numpy as np
 import torch
@@ -96,13 +97,15 @@ class OracleDarknet:
                     p[k] = p[k].detach().clone().requires_grad_(True)
 
     # ---- forward ----------------------------------------------------------------------
-    def _conv_block(self, i, d, x, mode, train_bn):
+    def _conv_block(self, i, d, x, mode, train_bn, stem_bf16=True):
         p = self.params[i]
         k, s = int(d["size"]), int(d["stride"])
         w = p["weight"]
         first = x.shape[1] == int(self.hyper["channels"]) and i == 0
-        if mode == "bf16" and not first:
+        if mode == "bf16" and (not first or stem_bf16):
             w = _bf16(w)
+            if first:
+                x = _bf16(x)
         y = F.conv2d(x, w, None, stride=s, padding=(k - 1) // 2)
         if int(d["batch_normalize"]):
             if train_bn:
@@ -118,7 +121,7 @@ class OracleDarknet:
             y = F.leaky_relu(y, 0.1)
         return y
 
-    def forward(self, x, targets=None, mode="fp32", train_bn=False, collect=False):
+    def forward(self, x, targets=None, mode="fp32", train_bn=False, collect=False, stem_bf16=True):
         """x [B,3,S,S] float32 tensor.  Returns outputs [B,N,5+C] (and loss if targets)."""
         img_dim = x.shape[2]
         outs_r, outs_f = [], []  # stored (rounded) and unrounded fp32 value of every layer output
@@ -128,7 +131,7 @@ class OracleDarknet:
         for i, d in enumerate(self.defs):
             t = d["type"]
             if t == "convolutional":
-                xf = self._conv_block(i, d, x, mode, train_bn)
+                xf = self._conv_block(i, d, x, mode, train_bn, stem_bf16)
                 is_head = not int(d["batch_normalize"])
                 x = xf if is_head else rnd(xf)
             elif t == "upsample":

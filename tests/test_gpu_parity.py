@@ -230,6 +230,38 @@ def test_stem_and_concat(dev):
     assert torch.equal(got.cpu(), ref)
 
 
+def test_stem_fused_kernel(dev):
+    """fused layer 0 + layer 1 vs torch-CPU with the same rounding points (bf16 image/filters, fp32 accumulate, bf16
+    intermediate, bf16 output).  Ragged size (72 -> 36: not a multiple of the 8x32 tile)."""
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(11)
+    B, H = 2, 72
+    x = torch.rand(B, 3, H, H, generator=g)
+    w0 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    s0, t0 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * (1.0 / np.sqrt(288))
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    mid = _bf16r(F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(w0), None, 1, 1) * s0.view(1, -1, 1, 1) + t0.view(1, -1, 1, 1), 0.1))
+    ref = _bf16r(F.leaky_relu(F.conv2d(mid, _bf16r(w1), None, 2, 1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1), 0.1))
+    w0p = torch.zeros(32, 32)
+    w0p[:, :27] = w0.reshape(32, 27)
+    xd, w0d, w1d = x.to(dev), w0p.to(torch.bfloat16).to(dev), w1.to(dev)
+    s0d, t0d, s1d, t1d = s0.to(dev), t0.to(dev), s1.to(dev), t1.to(dev)
+    packed = torch.empty(L.ay_packed_weight_bytes(64, 32, 3), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_conv_weights_bf16(ptr(w1d), ptr(packed), 64, 64, 32, 3, st))
+    Ho = H // 2
+    ob = torch.full((B, 4, Ho, Ho, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(L.ay_stem_s2_fused_fwd(ptr(xd), ptr(w0d), ptr(s0d), ptr(t0d), 1, ptr(packed), ptr(s1d), ptr(t1d), 1, ptr(ob), B, H, H, st))
+    got = torch.empty(B, 64, Ho, Ho, device=dev)
+    check(L.ay_blocked_bf16_to_nchw_f32(ptr(ob), ptr(got), B, 64, Ho, Ho, st))
+    got = got.cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -7 + 4e-3   # an intermediate that rounds the other way moves the sum by ~1e-3
+    assert float((err > bound).float().mean()) <= 1e-3 and float(err.max()) <= 0.05, (float((err > bound).float().mean()), float(err.max()))
+
+
 # ----------------------------------------------------------------------------------------- whole model
 _models = {}
 
