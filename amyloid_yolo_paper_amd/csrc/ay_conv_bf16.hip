@@ -595,10 +595,12 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     constexpr int W_SLAB = W_PIECES * 1024;
     constexpr int W_BASE = NK * PIX_SLAB;
     constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
-    constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);
-    constexpr int PW = (NPIECE + 7) / 8;                    // pieces per wave per stage (dummy-padded)
+    constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);     // + one piece that carries this item's scale/shift
+    constexpr int PW = (NPIECE + 1 + 7) / 8;                // pieces per wave per stage (dummy-padded)
     constexpr int DUMMY_BASE = NBUF * BUF_BYTES;
-    constexpr int LDS_BYTES = NBUF * BUF_BYTES + 1024;
+    constexpr int SS_BASE = DUMMY_BASE + 1024;              // 4 x 1 KiB [scale 128][shift 128], by item index & 3 (the loader
+                                                            // runs at most NBUF-1 <= 2 items ahead of the epilogue)
+    constexpr int LDS_BYTES = NBUF * BUF_BYTES + 5 * 1024;
     static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
     static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
     static_assert((KK2 * 2 * BN * 16) % 1024 == 0, "filter slab is whole DMA pieces");
@@ -631,8 +633,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     int src_off[PW];
     const uint8_t* ld_src = nullptr;
     const uint8_t* ld_w = nullptr;
-    int ld_item = item, ld_s = 0;
+    int ld_item = item, ld_s = 0, ld_par = 0;
     bool ld_done = false;
+    const float* ld_ss = nullptr;  // per-lane source of the scale/shift piece (nullptr: zero page)
     auto setup_loader = [&](int it) {
         const int cg = it % a.n_cgroups;
         const int pt = it / a.n_cgroups;
@@ -640,6 +643,8 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
         ld_src = a.src + (size_t)b * (a.cin / 16) * in_plane;
         ld_w = a.w + (size_t)cg * BN * 16;
+        // lanes 0..BN/4-1 fetch 4 scales each, lanes 32..32+BN/4-1 the shifts: LDS image [scale | pad to 128][shift]
+        ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int q = i * 8 + wave;
@@ -676,16 +681,20 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             } else if (q < NPIECE) {
                 g = wp + src_off[i];
                 dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
+            } else if (q == NPIECE) {
+                g = reinterpret_cast<const uint8_t*>(ld_ss);
+                dst = SS_BASE + ld_par * 1024;
             } else {
                 g = zero_page;
                 dst = DUMMY_BASE;
             }
-            if (src_off[i] < 0) g = zero_page + (lane & 3) * 16;
+            if (q == NPIECE ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
         }
         if (++ld_s == a.cin / (16 * NK)) {
             ld_s = 0;
+            ld_par = (ld_par + 1) & 3;
             ld_item += slots;
             if (ld_item < last)
                 setup_loader(ld_item);
@@ -704,6 +713,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
     const int nstages = a.cin / (16 * NK);
 
+    // de-phase the workgroups: identical items on every CU otherwise put all epilogues (the HBM-heavy phase) at the
+    // same instants and leave HBM idle during the MFMA phases
+    for (int k = 0; k < (slot & 3) * a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+
     // ---- prologue: NBUF-1 stages in flight, stage 0 landed -----------------------------------------------------
     setup_loader(item);
     issue_stage(0);
@@ -721,6 +734,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     asm volatile("" ::: "memory");
 
     int cur = 0;  // ring slot of the stage the MFMAs read
+    int par = 0;  // scale/shift region of the item the MFMAs work on
     while (true) {
         const int cg = item % a.n_cgroups;
         const int pt = item / a.n_cgroups;
@@ -793,9 +807,11 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             }
             if (++cur == NBUF) cur = 0;
         }
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4)>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4)>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+                                                                       reinterpret_cast<const float*>(lds + SS_BASE + par * 1024));
         if (!has_next) break;
         item = next_item;
+        par = (par + 1) & 3;
     }
 }
 
@@ -803,7 +819,7 @@ template <int KS, int STRIDE, int BN, int TH, int TW, int NK>
 constexpr int ring_depth() {
     constexpr int in_pix = ((TH - 1) * STRIDE + KS) * ((TW - 1) * STRIDE + KS);
     constexpr int buf = NK * (((2 * in_pix + 63) / 64) * 1024 + KS * KS * 2 * BN * 16);
-    return (3 * buf + 1024 <= 160 * 1024) ? 3 : 2;
+    return (3 * buf + 5 * 1024 <= 160 * 1024) ? 3 : 2;
 }
 
 // AY_CONV_MODE: 1 = V1 (4 waves, register staging), 2 = V2 (8 waves, DMA filters), 3 = V3 persistent,
@@ -847,6 +863,8 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     a.leaky = d->leaky;
     static const int dbg = getenv("AY_DBG") ? atoi(getenv("AY_DBG")) : 0;
     a.dbg = dbg;
+    static const int stagger = getenv("AY_STAGGER") ? atoi(getenv("AY_STAGGER")) : 0;
+    a.stagger = stagger;
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);

@@ -15,6 +15,8 @@ struct ConvArgs {
     int tiles_x, tiles_y, n_cgroups;
     int leaky;
     int dbg;  // timing experiments only (AY_DBG): 1 = no staging in the stage loop, 2 = no MFMA phase
+    int stagger;  // ring kernel: start workgroup (slot & 3) after slot&3 x stagger x ~4 us, so that the CUs' epilogue
+                  // (HBM) phases do not coincide
 };
 
 // ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
@@ -59,12 +61,38 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
     }
 }
 
+// RES_INLINE: the residual is loaded here, one 32-pixel block ahead of its use (large wave tiles cannot hold all of it).
+// ss_lds != nullptr: per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift],
+// so the epilogue issues no vector-memory loads that would have to wait behind its own stores.
 template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
-                                              int wm, int wn, int c, int hh, int y0, int x0) {
+                                              int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr) {
     const int CP = a.cout_pad;
     const size_t out_plane_px = (size_t)a.hout * a.wout;
     const int cbase = cg * BN + wm * MT * 32;
+    const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
+
+    uint2 rres[2][2][2];  // [ping/pong][quad pair][quad]: residual of one (n, m) 32x32 block, loaded one block ahead
+    auto load_res = [&](int t, uint2 (&r)[2][2]) {
+        const int n = t / MT, m = t % MT;
+        const int p = (wn * NT + n) * 32 + c;
+        const int oy = y0 + p / TW, ox = x0 + p % TW;
+        const bool ok = (oy < a.hout) && (ox < a.wout);
+        const size_t pix = (size_t)oy * a.wout + ox;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            const size_t plane = (size_t)b * (CP / 16) + ((cbase + m * 32 + qp * 16) >> 4);
+            uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
+            if (ok) {
+                const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
+                v0 = *reinterpret_cast<const uint2*>(rp);
+                v1 = *reinterpret_cast<const uint2*>(rp + 16);
+            }
+            r[qp][0] = v0;
+            r[qp][1] = v1;
+        }
+    };
+    if constexpr (HAS_RES && RES_INLINE) load_res(0, rres[0]);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
@@ -73,15 +101,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            if constexpr (HAS_RES && RES_INLINE) {
+                if (n * MT + m + 1 < NT * MT) load_res(n * MT + m + 1, rres[(n * MT + m + 1) & 1]);
+            }
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
                 const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
                 float v[4], w[4];
                 {
-                    const float4 s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
-                    const float4 t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
-                    const float4 s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
-                    const float4 t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
+                    float4 s0, t0, s1, t1;
+                    if (ss_lds) {
+                        const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;
+                        s0 = *reinterpret_cast<const float4*>(ss_lds + l0);
+                        t0 = *reinterpret_cast<const float4*>(ss_lds + 128 + l0);
+                        s1 = *reinterpret_cast<const float4*>(ss_lds + l0 + 8);
+                        t1 = *reinterpret_cast<const float4*>(ss_lds + 128 + l0 + 8);
+                    } else {
+                        s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
+                        t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
+                        s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
+                        t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
+                    }
                     const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
                     const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
@@ -107,15 +147,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 } else {
                     const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
                     if constexpr (HAS_RES) {
-                        // residual (prefetched in the accumulator's own layout) added in fp32 before the single rounding
+                        // residual (in the accumulator's own layout) added in fp32 before the single bf16 rounding
                         uint2 r0v, r1v;
-                        if constexpr (RES_INLINE) {  // large wave tiles: no room to hold the whole residual in registers
-                            r0v = r1v = make_uint2(0, 0);
-                            if (ok) {
-                                const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                                r0v = *reinterpret_cast<const uint2*>(rp);
-                                r1v = *reinterpret_cast<const uint2*>(rp + 16);
-                            }
+                        if constexpr (RES_INLINE) {
+                            r0v = rres[(n * MT + m) & 1][qp][0];
+                            r1v = rres[(n * MT + m) & 1][qp][1];
                         } else {
                             r0v = rr.r[m][n][qp][0];
                             r1v = rr.r[m][n][qp][1];

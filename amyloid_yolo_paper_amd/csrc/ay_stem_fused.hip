@@ -65,6 +65,24 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) wa[ks] = *reinterpret_cast<const bf16x8*>(s.w0 + c * 32 + 16 * ks + 8 * hh);
 
+    // per-lane constants of the stem MFMA: image-tile offset of k = 16*ks + 8*hh + e (-1: zero padding of K), affine
+    int koff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * hh + e;
+            koff[ks][e] = k < 27 ? ((k / 9) * IH + (k % 9) / 3) * IW + k % 3 : -1;
+        }
+    float sc0[4][4], sh0[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc0[q][j] = s.scale0[8 * q + 4 * hh + j];
+            sh0[q][j] = s.shift0[8 * q + 4 * hh + j];
+        }
+
     float rimg[NIMG];
     auto load_image = [&](int it) {
         const int pt = it;  // one channel group: item == pixel tile
@@ -111,6 +129,7 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
             const int P = blk * 32 + c;
             const int sy = P / SW, sx = P % SW;  // stem pixel inside the halo tile (P >= S_PIX: padding rows of the slab)
             const bool inside = P < S_PIX;
+            const float* ip = img + (inside ? sy * IW + sx : 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -119,18 +138,10 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
                 unsigned pk[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    float v[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int k = 16 * ks + 8 * hh + 2 * jj + e;
-                        float t = 0.f;
-                        if (k < 27 && inside) {
-                            const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
-                            t = img[(ci * IH + sy + kh) * IW + sx + kw];
-                        }
-                        v[e] = t;
-                    }
-                    pk[jj] = pack2bf(v[0], v[1]);
+                    const int o0 = koff[ks][2 * jj], o1 = koff[ks][2 * jj + 1];
+                    const float v0 = o0 >= 0 ? ip[o0] : 0.f;
+                    const float v1 = o1 >= 0 ? ip[o1] : 0.f;
+                    pk[jj] = pack2bf(v0, v1);
                 }
                 const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], __builtin_bit_cast(bf16x8, pv), acc, 0, 0, 0);
@@ -141,14 +152,10 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
             const bool real = inside && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ch0 = 8 * q + 4 * hh;
-                const float4 sc = *reinterpret_cast<const float4*>(s.scale0 + ch0);
-                const float4 sh = *reinterpret_cast<const float4*>(s.shift0 + ch0);
-                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[4 * q + j] * scv[j] + shv[j];
+                    float t = acc[4 * q + j] * sc0[q][j] + sh0[q][j];
                     if (s.leaky0) t = t > 0.f ? t : 0.1f * t;
                     o[j] = real ? t : 0.f;
                 }
@@ -223,6 +230,7 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     a.n_cgroups = 1;
     a.leaky = leaky1;
     a.dbg = 0;
+    a.stagger = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;
     AY_CHECK_ARG(n_items > 0 && n_items < 0x7fffffffLL, "ay_stem_s2_fused_fwd: grid");
     const int per_xcd = (int)((n_items + 7) / 8);

@@ -9,7 +9,7 @@ d = sys.argv[1]
 f = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "stem_conv" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "stem" in r["Kernel_Name"]]
 seq = rows[idx[-1]:]
 m = Darknet(cfg_gen.write_cfg(int(sys.argv[2]) if len(sys.argv) > 2 else 3, "/tmp/cfgt"))
 convs = [(i, e) for i, e in enumerate(m._graph) if e["type"] == "convolutional"]
@@ -21,6 +21,11 @@ for r in seq:
         i, e = convs[ci]; ci += 1
         S = 1024 >> e["log2_down"]
         fl = 2 * 64 * S * S * e["cout"] * e["cin"] * e["k"] ** 2
+        if "stem_s2_fused" in n:  # layers 0 and 1 in one kernel
+            i, e1 = convs[ci]; ci += 1
+            S1 = 1024 >> e1["log2_down"]
+            fl += 2 * 64 * S1 * S1 * e1["cout"] * e1["cin"] * e1["k"] ** 2
+            e = dict(e1, cin=3)
         key = f"{e['cin']:4d}->{e['cout']:4d} k{e['k']} s{e['stride']} @{S:4d} {'res' if e['fuse_into_shortcut'] else '   '}"
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
         tot += dur
