@@ -52,6 +52,13 @@ _SIGS = {
     "ay_yolo_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "ay_yolo_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
     "ay_adam_flat": (_I, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _F, _P]),
+    "ay_bn_train_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_bn_train_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_accumulate_bf16": (_I, [_P, _P, _SZ, _P]),
+    "ay_slice_accumulate_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ay_zero_insert_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ay_pack_dgrad_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_conv_wgrad_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

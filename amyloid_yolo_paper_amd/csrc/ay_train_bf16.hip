@@ -1,0 +1,338 @@
+// Training-step kernels of the bf16 MFMA path (activations and activation gradients in blocked bf16, statistics and
+// parameter gradients in fp32/fp64): train-mode BatchNorm split into a statistics pass and an apply pass around the MFMA
+// convolution (models.py:43-45), its backward, gradient plumbing for shortcut / route / upsample (models.py:86-96,244-248),
+// filter re-packing that turns the forward convolution kernel into the data-gradient kernel, and zero insertion for the
+// stride-2 data gradient.  All of these are bandwidth-bound elementwise / reduction passes over [B][C/16][H][W][16] bf16.
+#include "ay_common.h"
+
+namespace ay {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf2f((uint16_t)(u[j] & 0xffffu));
+        f[2 * j + 1] = bf2f((uint16_t)(u[j] >> 16));
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// ---- per-channel sums over (B,H,W) of a blocked bf16 tensor: sums[c] += sum z, sums[C + c] += sum z^2 (fp64 atomics)
+// grid (chunks, planes, batch); one thread = one 16-byte unit (pixel, 8 channels); lanes of equal parity share channels.
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ a, const uint4* __restrict__ zt,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
+                                                      double* __restrict__ sums, int C, int HW) {
+    const int plane = blockIdx.y, b = blockIdx.z;
+    const int CP = gridDim.y;
+    const size_t base = ((size_t)b * CP + plane) * HW * 2;
+    const int half = threadIdx.x & 1;
+    const int c0 = plane * 16 + half * 8;
+    float s1[8], s2[8], mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = s2[j] = 0.f;
+        if (BWD) {
+            const int c = c0 + j < C ? c0 + j : C - 1;
+            mu[j] = mean[c];
+            is[j] = invstd[c];
+            ga[j] = gamma[c];
+            be[j] = beta[c];
+        }
+    }
+    const int units = HW * 2;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {  // stride keeps the unit parity
+        float f[8];
+        unpack8(a[base + u], f);
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1[j] += f[j];
+                s2[j] += f[j] * f[j];
+            }
+        } else {  // a = dy, zt = z: s1 = sum dpre, s2 = sum dpre * xhat
+            float z[8];
+            unpack8(zt[base + u], z);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (z[j] - mu[j]) * is[j];
+                const float pre = xh * ga[j] + be[j];
+                const float d = (leaky && !(pre > 0.f)) ? 0.1f * f[j] : f[j];
+                s1[j] += d;
+                s2[j] += d * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) {
+            s1[j] += __shfl_xor(s1[j], off);
+            s2[j] += __shfl_xor(s2[j], off);
+        }
+    }
+    if ((threadIdx.x & 63) < 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < C) {
+                atomicAdd(&sums[c0 + j], (double)s1[j]);
+                atomicAdd(&sums[C + c0 + j], (double)s2[j]);
+            }
+    }
+}
+
+// finalize forward statistics: mean, invstd, running stats (PyTorch semantics)
+__global__ void bn_finalize_fwd_kernel(const double* sums, double n, float eps, float momentum, float* running_mean, float* running_var,
+                                       float* save_mean, float* save_invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / n;
+    double var = sums[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+__global__ void bn_finalize_bwd_kernel(const double* sums, float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[c];
+    dgamma[c] = (float)sums[C + c];
+}
+
+// y = bf16( leaky(gamma * (z - mean) * invstd + beta) [+ skip] )
+__global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int leaky, const uint4* __restrict__ skip,
+                                                       uint4* __restrict__ y, int C, int CP, int HW, size_t units) {
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        const int half = (int)(u & 1);
+        const int plane = (int)((u / 2 / HW) % CP);
+        const int c0 = plane * 16 + half * 8;
+        float f[8], s[8];
+        unpack8(z[u], f);
+        if (skip) unpack8(skip[u], s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j < C ? c0 + j : C - 1;
+            float v = (f[j] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+            if (leaky) v = v > 0.f ? v : 0.1f * v;
+            if (skip) v += s[j];
+            f[j] = c0 + j < C ? v : 0.f;
+        }
+        y[u] = pack8(f);
+    }
+}
+
+// dz = gamma*invstd/n * (n*dpre - dbeta - xhat*dgamma), dpre = dy * leaky'(pre)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
+                                                           const double* __restrict__ sums, float n, uint4* __restrict__ dz, int C, int CP,
+                                                           int HW, size_t units) {
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        const int half = (int)(u & 1);
+        const int plane = (int)((u / 2 / HW) % CP);
+        const int c0 = plane * 16 + half * 8;
+        float d[8], zz[8];
+        unpack8(dy[u], d);
+        unpack8(z[u], zz);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j < C ? c0 + j : C - 1;
+            const float xh = (zz[j] - mean[c]) * invstd[c];
+            const float pre = xh * gamma[c] + beta[c];
+            const float dp = (leaky && !(pre > 0.f)) ? 0.1f * d[j] : d[j];
+            const float k = gamma[c] * invstd[c] / n;
+            const float v = k * (n * dp - (float)sums[c] - xh * (float)sums[C + c]);
+            d[j] = c0 + j < C ? v : 0.f;
+        }
+        dz[u] = pack8(d);
+    }
+}
+
+// dst += src (bf16, fp32 add, one rounding)
+__global__ void accum_bf16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t units) {
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        float a[8], b[8];
+        unpack8(dst[u], a);
+        unpack8(src[u], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        dst[u] = pack8(a);
+    }
+}
+
+// route / upsample backward on blocked tensors: dsrc[b][pl][ys][xs] (+)= sum over the (1<<up)^2 children of dout[b][p0+pl][y][x]
+__global__ void slice_accum_bf16_kernel(const uint4* __restrict__ dout, uint4* __restrict__ dsrc, int B, int psrc, int ptot, int p0, int H,
+                                        int W, int up, int accumulate) {
+    const int hs = H >> up, ws = W >> up, f = 1 << up;
+    const size_t units = (size_t)B * psrc * hs * ws * 2;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        const int half = (int)(u & 1);
+        size_t t = u >> 1;
+        const int xs = (int)(t % ws);
+        t /= ws;
+        const int ys = (int)(t % hs);
+        t /= hs;
+        const int pl = (int)(t % psrc);
+        const int b = (int)(t / psrc);
+        float acc[8];
+        if (accumulate)
+            unpack8(dsrc[u], acc);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        }
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) {
+                float v[8];
+                unpack8(dout[((((size_t)b * ptot + p0 + pl) * H + ys * f + dy) * W + xs * f + dx) * 2 + half], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        dsrc[u] = pack8(acc);
+    }
+}
+
+// out[b][pl][2y][2x] = in[b][pl][y][x], zeros elsewhere (stride-2 data gradient as a stride-1 convolution)
+__global__ void zero_insert_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int planes_total, int H, int W, int HO, int WO) {
+    const size_t units = (size_t)planes_total * HO * WO * 2;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        const int half = (int)(u & 1);
+        size_t t = u >> 1;
+        const int x = (int)(t % WO);
+        t /= WO;
+        const int y = (int)(t % HO);
+        const size_t pl = t / HO;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!(x & 1) && !(y & 1) && (y >> 1) < H && (x >> 1) < W) v = in[((pl * H + (y >> 1)) * W + (x >> 1)) * 2 + half];
+        out[u] = v;
+    }
+}
+
+// filters for the data gradient: the forward kernel computes dx = conv(dz, W') with W'[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw];
+// packed as [Cout/16 (K chunks)][tap][half][CinPad][8] bf16
+__global__ void pack_dgrad_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cout_pad16, int cin,
+                                          int cin_pad, int ks) {
+    const int kk2 = ks * ks;
+    const size_t total = (size_t)(cout_pad16 / 16) * kk2 * 2 * cin_pad * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % 8);
+        size_t t = i / 8;
+        const int ci = (int)(t % cin_pad);
+        t /= cin_pad;
+        const int half = (int)(t % 2);
+        t /= 2;
+        const int tap = (int)(t % kk2);
+        const int chunk = (int)(t / kk2);
+        const int co = chunk * 16 + half * 8 + j;
+        const int kh = tap / ks, kw = tap % ks;
+        float v = 0.f;
+        if (co < cout && ci < cin) v = w[(((size_t)co * cin + ci) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)];
+        out[i] = f2bf(v);
+    }
+}
+
+static inline unsigned gridu(size_t units) {
+    size_t g = (units + 255) / 256;
+    if (g > 65535) g = 65535;
+    return (unsigned)(g ? g : 1);
+}
+
+}  // namespace ay
+
+using namespace ay;
+
+extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                                    double* sums_ws /* 2*C doubles */, int batch, int channels, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(z && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && sums_ws, "ay_bn_train_fwd_bf16: null");
+    hipStream_t st = S(stream);
+    const int CP = (channels + 15) / 16, HW = h * w;
+    AY_CHECK_ARG(batch <= 65535, "ay_bn_train_fwd_bf16: batch");
+    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
+        set_error("memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    int gx = (HW * 2 + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(gx, CP, batch), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, 0, sums_ws, channels, HW);
+    AY_CHECK_LAUNCH("bn_sums_kernel");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, (double)batch * HW, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd, channels);
+    AY_CHECK_LAUNCH("bn_finalize_fwd_kernel");
+    const size_t units = (size_t)batch * CP * HW * 2;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(gridu(units)), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta, leaky,
+                       (const uint4*)skip, (uint4*)y, channels, CP, HW, units);
+    AY_CHECK_LAUNCH("bn_apply_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, int batch,
+                                    int channels, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(dy && z && gamma && beta && save_mean && save_invstd && dz && dgamma && dbeta && sums_ws, "ay_bn_train_bwd_bf16: null");
+    hipStream_t st = S(stream);
+    const int CP = (channels + 15) / 16, HW = h * w;
+    AY_CHECK_ARG(batch <= 65535, "ay_bn_train_bwd_bf16: batch");
+    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
+        set_error("memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    int gx = (HW * 2 + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(gx, CP, batch), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
+                       gamma, beta, leaky, sums_ws, channels, HW);
+    AY_CHECK_LAUNCH("bn_sums_kernel<bwd>");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels);
+    AY_CHECK_LAUNCH("bn_finalize_bwd_kernel");
+    const size_t units = (size_t)batch * CP * HW * 2;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gridu(units)), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
+                       gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW, units);
+    AY_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_accumulate_bf16(void* dst, const void* src, size_t n_elems, ay_stream_t stream) {
+    AY_CHECK_ARG(dst && src && n_elems % 8 == 0, "ay_accumulate_bf16: bad args");
+    hipLaunchKernelGGL(accum_bf16_kernel, dim3(gridu(n_elems / 8)), dim3(256), 0, S(stream), (uint4*)dst, (const uint4*)src, n_elems / 8);
+    AY_CHECK_LAUNCH("accum_bf16_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_slice_accumulate_bf16(const void* dout, void* dsrc, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
+                                        int accumulate, ay_stream_t stream) {
+    AY_CHECK_ARG(dout && dsrc && csrc % 16 == 0 && ctotal % 16 == 0 && c0 % 16 == 0 && (up == 0 || up == 1), "ay_slice_accumulate_bf16: bad args");
+    const size_t units = (size_t)batch * (csrc / 16) * (h >> up) * (w >> up) * 2;
+    hipLaunchKernelGGL(slice_accum_bf16_kernel, dim3(gridu(units)), dim3(256), 0, S(stream), (const uint4*)dout, (uint4*)dsrc, batch, csrc / 16,
+                       ctotal / 16, c0 / 16, h, w, up, accumulate);
+    AY_CHECK_LAUNCH("slice_accum_bf16_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_zero_insert_bf16(const void* in, void* out, int batch, int channels, int h, int w, int ho, int wo, ay_stream_t stream) {
+    AY_CHECK_ARG(in && out && channels % 16 == 0 && ho >= 2 * h - 1 && wo >= 2 * w - 1, "ay_zero_insert_bf16: bad args");
+    const int planes = batch * (channels / 16);
+    const size_t units = (size_t)planes * ho * wo * 2;
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(gridu(units)), dim3(256), 0, S(stream), (const uint4*)in, (uint4*)out, planes, h, w, ho, wo);
+    AY_CHECK_LAUNCH("zero_insert_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int cin, int cin_pad, int ksize, ay_stream_t stream) {
+    AY_CHECK_ARG(w_oihw && packed && cin_pad >= cin && cin_pad % 32 == 0, "ay_pack_dgrad_weights_bf16: bad args");
+    const int cout_pad16 = (cout + 15) / 16 * 16;
+    const size_t total = (size_t)(cout_pad16 / 16) * ksize * ksize * 2 * cin_pad * 8;
+    hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3(gridu(total)), dim3(256), 0, S(stream), w_oihw, (uint16_t*)packed, cout, cout_pad16, cin,
+                       cin_pad, ksize);
+    AY_CHECK_LAUNCH("pack_dgrad_weights_kernel");
+    return AY_OK;
+}

@@ -1,0 +1,228 @@
+// Weight gradient of a convolution on the MFMA path:
+//     dW[co][ci][kh][kw] = sum_{b,oy,ox} dz[b][co][oy][ox] * x[b][ci][oy*s - pad + kh][ox*s - pad + kw]
+// (autograd of nn.Conv2d, models.py:33-40).  The contraction runs over PIXELS, while both tensors are stored
+// [plane][pixel][16 channels]; v_mfma_f32_16x16x32_bf16 wants, per lane, 8 consecutive k (= pixels) of one row (= channel).
+// ds_read_b64_tr_b16 does exactly that transpose on the way out of LDS (4 pixel rows x 16 channels per 16 lanes), so the
+// tiles are staged by plain lane-linear LDS-DMA and never re-laid-out (scripts/micro/tr_mfma_test.hip pins the mapping).
+//
+// Workgroup (8 waves): 8 co planes (128 channels) x 4 ci planes (64 channels) x all taps; wave (cw, iw) owns 4 co planes x
+// 1 ci plane x taps = 36 accumulator tiles of 16x16 (3x3).  K step = one 32-pixel segment of one output row: dz tile
+// 8 x 32 px, x tile 4 planes x 3 rows x 34 px (65 for stride 2).  Segments are dealt round-robin over a split-K grid
+// dimension and the partial filters are added to dW with fp32 atomics (dW is zeroed first).
+// LDS slots are XOR-swizzled (slot = px ^ ((px>>3 & 1) << 2)), through the DMA source address, so that the two 4-row blocks
+// a 32-lane half reads land on different banks.
+#include "ay_common.h"
+
+namespace ay {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const uint8_t* x;
+    const uint8_t* dz;
+    float* dw;
+    int B, cin, cout, CIP, COP, hin, win, ho, wo;
+    int nseg_x, total_segs;
+};
+
+__device__ __attribute__((aligned(64))) uint32_t g_wgrad_zero_page[16];
+
+__device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2); }
+
+template <int KS, int STRIDE>
+__global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int KK2 = KS * KS;
+    constexpr int CO_PL = 8, CI_PL = 4, COW = 4;       // planes per workgroup; co planes per wave
+    constexpr int XW = 31 * STRIDE + KS;                // input pixels per row of a segment
+    constexpr int DZ_UNITS = CO_PL * 32 * 2;            // 16-byte units
+    constexpr int X_UNITS = CI_PL * KS * XW * 2;
+    constexpr int DZ_PIECES = DZ_UNITS / 64;
+    constexpr int X_PIECES = (X_UNITS + 63) / 64;
+    constexpr int NPIECE = DZ_PIECES + X_PIECES;
+    constexpr int PW = (NPIECE + 7) / 8;
+    constexpr int X_BASE = DZ_PIECES * 1024;
+    constexpr int BUF_BYTES = NPIECE * 1024;
+    constexpr int NBUF = 4;
+    constexpr int DUMMY = NBUF * BUF_BYTES;
+    static_assert(NBUF * BUF_BYTES + 1024 <= 160 * 1024, "LDS");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF * BUF_BYTES + 1024];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave / CI_PL, iw = wave % CI_PL;
+    const int cob = blockIdx.x, cib = blockIdx.y;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_wgrad_zero_page);
+
+    // segments of this workgroup: blockIdx.z, + gridDim.z, ...
+    int seg = blockIdx.z;
+    const int nstep = (a.total_segs - seg + (int)gridDim.z - 1) / (int)gridDim.z;
+    if (nstep <= 0) return;
+
+    auto issue = [&](int sg, int buf) {
+        const int xs = sg % a.nseg_x;
+        const int oy = (sg / a.nseg_x) % a.ho;
+        const int b = sg / (a.nseg_x * a.ho);
+        const int ox0 = xs * 32;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int qn = i * 8 + wave;  // wave-uniform piece id
+            const uint8_t* src = zero_page + (lane & 3) * 16;
+            int dst = DUMMY;
+            if (qn < DZ_PIECES) {
+                const int u = qn * 64 + lane;
+                const int half = u & 1, slot = (u >> 1) & 31, pl = u >> 6;
+                const int ox = ox0 + swz(slot);
+                const int cpl = cob * CO_PL + pl;
+                if (cpl < a.COP && ox < a.wo) src = a.dz + ((((size_t)b * a.COP + cpl) * a.ho + oy) * a.wo + ox) * 32 + half * 16;
+                dst = buf * BUF_BYTES + qn * 1024;
+            } else if (qn < NPIECE) {
+                const int u = (qn - DZ_PIECES) * 64 + lane;
+                if (u < X_UNITS) {
+                    const int half = u & 1;
+                    const int t = u >> 1;
+                    const int slot = t % XW, sgi = t / XW;  // sgi = ipl * KS + kh
+                    const int kh = sgi % KS, ipl = sgi / KS;
+                    const int iy = oy * STRIDE - PAD + kh;
+                    const int ix = ox0 * STRIDE - PAD + swz(slot);
+                    const int cpl = cib * CI_PL + ipl;
+                    if (cpl < a.CIP && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                        src = a.x + ((((size_t)b * a.CIP + cpl) * a.hin + iy) * a.win + ix) * 32 + half * 16;
+                }
+                dst = buf * BUF_BYTES + qn * 1024;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
+        }
+    };
+
+    // fragment addresses (buffer-relative)
+    int aoff[2], boff[KS][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = 8 * g + 4 * s + q;
+        aoff[s] = ((cw * COW) * 32 + swz(r)) * 32 + p * 8;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) boff[kw][s] = X_BASE + ((iw * KS) * XW + swz(r * STRIDE + kw)) * 32 + p * 8;
+    }
+
+    f32x4 acc[COW][KK2];
+#pragma unroll
+    for (int j = 0; j < COW; ++j)
+#pragma unroll
+        for (int t = 0; t < KK2; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: up to NBUF-1 stages in flight
+    int issued = 0;
+    for (; issued < NBUF - 1 && issued < nstep; ++issued) issue(seg + issued * (int)gridDim.z, issued);
+    if (issued >= 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+    else if (issued == 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int k = 0; k < nstep; ++k) {
+        const int cur = k & (NBUF - 1);
+        if (issued < nstep) {
+            issue(seg + issued * (int)gridDim.z, issued & (NBUF - 1));
+            ++issued;
+        }
+        const uint8_t* L = lds + cur * BUF_BYTES;
+        bf16x8 af[COW];
+#pragma unroll
+        for (int j = 0; j < COW; ++j) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[0] + j * 1024));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[1] + j * 1024));
+            const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            __builtin_memcpy(&af[j], v, 16);
+        }
+#pragma unroll
+        for (int t = 0; t < KK2; ++t) {
+            const int kh = t / KS, kw = t % KS;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][0] + kh * XW * 32));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][1] + kh * XW * 32));
+            const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16x8 bfr;
+            __builtin_memcpy(&bfr, v, 16);
+#pragma unroll
+            for (int j = 0; j < COW; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[j][t], 0, 0, 0);
+        }
+        if (k + 1 < nstep) {
+            const int ahead = issued - (k + 1);  // stages issued beyond k: k+1 .. issued-1 ; k+1 must land, the rest may fly
+            if (ahead >= 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // D: row (co) = 4*(lane>>4) + reg, col (ci) = lane & 15
+    const int ci = (cib * CI_PL + iw) * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < COW; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = (cob * CO_PL + cw * COW + j) * 16 + 4 * g + r;
+            if (co < a.cout && ci < a.cin) {
+                float* o = a.dw + ((size_t)co * a.cin + ci) * KK2;
+#pragma unroll
+                for (int t = 0; t < KK2; ++t) atomicAdd(o + t, acc[j][t][r]);
+            }
+        }
+    }
+}
+
+}  // namespace ay
+
+extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream) {
+    using namespace ay;
+    AY_CHECK_ARG(d && x_blocked && dz_blocked && dw_oihw, "ay_conv_wgrad_bf16: null");
+    AY_CHECK_ARG(d->cin % 16 == 0, "ay_conv_wgrad_bf16: cin %d not a multiple of 16", d->cin);
+    AY_CHECK_ARG((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 1), "ay_conv_wgrad_bf16: shape");
+    hipStream_t st = S(stream);
+    WgradArgs a;
+    a.x = (const uint8_t*)x_blocked;
+    a.dz = (const uint8_t*)dz_blocked;
+    a.dw = dw_oihw;
+    a.B = d->batch;
+    a.cin = d->cin;
+    a.cout = d->cout;
+    a.CIP = d->cin / 16;
+    a.COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
+    a.hin = d->hin;
+    a.win = d->win;
+    a.ho = d->hout;
+    a.wo = d->wout;
+    a.nseg_x = (d->wout + 31) / 32;
+    const long long total = (long long)d->batch * d->hout * a.nseg_x;
+    AY_CHECK_ARG(total > 0 && total < 0x7fffffffLL, "ay_conv_wgrad_bf16: too many segments");
+    a.total_segs = (int)total;
+    const int cob = (a.COP + 7) / 8, cib = (a.CIP + 3) / 4;
+    long long ks = (1024 + (long long)cob * cib - 1) / ((long long)cob * cib);  // ~4 workgroups per CU in flight overall
+    if (ks > total) ks = total;
+    if (ks > 65535) ks = 65535;
+    if (ks < 1) ks = 1;
+    if (hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ksize * d->ksize, st) != hipSuccess) {
+        set_error("ay_conv_wgrad_bf16: memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    dim3 grid(cob, cib, (unsigned)ks), block(512);
+    if (d->ksize == 3 && d->stride == 1)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1>), grid, block, 0, st, a);
+    else if (d->ksize == 3)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), grid, block, 0, st, a);
+    AY_CHECK_LAUNCH("wgrad_bf16_kernel");
+    return AY_OK;
+}

@@ -174,6 +174,31 @@ int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_tar
 int ay_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, ay_stream_t stream);
 
+/* ---- training step, bf16 MFMA path (blocked bf16 activations and activation gradients) ------------- */
+
+/* Train-mode BatchNorm + LeakyReLU (+ fused shortcut add of `skip`) around the MFMA convolution: statistics pass (fp64
+ * atomics into sums_ws[2*C]), finalize (mean/invstd/running stats, PyTorch momentum semantics), apply pass -> y. */
+int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                         double* sums_ws, int batch, int channels, int h, int w, ay_stream_t stream);
+/* dy (gradient of the block output, before the shortcut add) -> dz, dgamma, dbeta; leaky' is taken from the recomputed
+ * pre-activation gamma*xhat+beta */
+int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, int batch,
+                         int channels, int h, int w, ay_stream_t stream);
+int ay_accumulate_bf16(void* dst, const void* src, size_t n_elems, ay_stream_t stream);
+/* route / nearest-upsample backward on blocked tensors (channel counts multiples of 16) */
+int ay_slice_accumulate_bf16(const void* dout, void* dsrc, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
+                             int accumulate, ay_stream_t stream);
+/* stride-2 data gradient = stride-1 convolution of the zero-inserted output gradient: out[2y][2x] = in[y][x] */
+int ay_zero_insert_bf16(const void* in, void* out, int batch, int channels, int h, int w, int ho, int wo, ay_stream_t stream);
+/* filters that make ay_conv_fwd_bf16 compute the data gradient: W'[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw], packed
+ * [ceil(cout/16)][k*k][2][cin_pad][8]; use with desc{cin=ceil16(cout), cout=cin, cout_pad=cin_pad, stride 1}. */
+int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int cin, int cin_pad, int ksize, ay_stream_t stream);
+/* weight gradient on the MFMA path: dW (OIHW fp32, overwritten) from blocked bf16 input x and output gradient dz
+ * (desc as in the forward; cout_pad = channels of dz's planes) */
+int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
