@@ -25,10 +25,9 @@ template <bool BWD>
 __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ a, const uint4* __restrict__ zt,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
-                                                      double* __restrict__ sums, int C, int HW) {
-    const int plane = blockIdx.y, b = blockIdx.z;
+                                                      double* __restrict__ sums, int C, int HW, int B) {
+    const int plane = blockIdx.y;
     const int CP = gridDim.y;
-    const size_t base = ((size_t)b * CP + plane) * HW * 2;
     const int half = threadIdx.x & 1;
     const int c0 = plane * 16 + half * 8;
     float s1[8], s2[8], mu[8], is[8], ga[8], be[8];
@@ -44,7 +43,11 @@ __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ 
         }
     }
     const int units = HW * 2;
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {  // stride keeps the unit parity
+    const long long all_units = (long long)B * units;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < all_units; v += (long long)gridDim.x * 256) {  // even strides keep the parity
+        const int b = (int)(v / units);
+        const int u = (int)(v % units);
+        const size_t base = ((size_t)b * CP + plane) * HW * 2;
         float f[8];
         unpack8(a[base + u], f);
         if (!BWD) {
@@ -256,15 +259,15 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
     AY_CHECK_ARG(z && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && sums_ws, "ay_bn_train_fwd_bf16: null");
     hipStream_t st = S(stream);
     const int CP = (channels + 15) / 16, HW = h * w;
-    AY_CHECK_ARG(batch <= 65535, "ay_bn_train_fwd_bf16: batch");
     if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    int gx = (HW * 2 + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(gx, CP, batch), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, 0, sums_ws, channels, HW);
+    long long gxl = ((long long)batch * HW * 2 + 4 * 256 - 1) / (4 * 256);  // >= 4 units per thread
+    const int cap = CP >= 64 ? 8 : (CP >= 16 ? 32 : 128);                      // ~512-2048 workgroups in all
+    const int gx = (int)(gxl < 1 ? 1 : (gxl > cap ? cap : gxl));
+    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(gx, CP), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, 0, sums_ws, channels, HW, batch);
     AY_CHECK_LAUNCH("bn_sums_kernel");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, (double)batch * HW, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, channels);
@@ -282,15 +285,15 @@ extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* 
     AY_CHECK_ARG(dy && z && gamma && beta && save_mean && save_invstd && dz && dgamma && dbeta && sums_ws, "ay_bn_train_bwd_bf16: null");
     hipStream_t st = S(stream);
     const int CP = (channels + 15) / 16, HW = h * w;
-    AY_CHECK_ARG(batch <= 65535, "ay_bn_train_bwd_bf16: batch");
     if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    int gx = (HW * 2 + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(gx, CP, batch), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
-                       gamma, beta, leaky, sums_ws, channels, HW);
+    long long gxl = ((long long)batch * HW * 2 + 4 * 256 - 1) / (4 * 256);
+    const int cap = CP >= 64 ? 8 : (CP >= 16 ? 32 : 128);
+    const int gx = (int)(gxl < 1 ? 1 : (gxl > cap ? cap : gxl));
+    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(gx, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
+                       gamma, beta, leaky, sums_ws, channels, HW, batch);
     AY_CHECK_LAUNCH("bn_sums_kernel<bwd>");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels);
     AY_CHECK_LAUNCH("bn_finalize_bwd_kernel");

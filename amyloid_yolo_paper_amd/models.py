@@ -291,15 +291,22 @@ class Darknet(nn.Module):
         """Reference semantics (``models.py:237-255``): returns the CPU tensor ``[B, N, 5+C]``; the device copy is
         kept as ``out._ay_device`` so ``non_max_suppression`` does not upload it again."""
         if targets is not None:
-            # training step (fp32 reference-precision path this round; see train_engine.py): loss carries the autograd
-            # node whose backward runs the HIP dgrad/wgrad/BN/loss kernels and fills every parameter's .grad
-            from .train_engine import TrainStep
-            loss, dev_out = TrainStep.apply(self, x, targets, *self.parameters())
+            # training step: loss carries the autograd node whose backward runs the HIP dgrad / wgrad / BN / loss kernels
+            # and fills every parameter's .grad.  precision="bf16": matrix-core path (train_engine_bf16.py);
+            # precision="fp32": reference-precision path pinned by the golden training fixtures (train_engine.py).
+            if self.precision == "bf16" and self.training:
+                from .train_engine_bf16 import TrainStepBf16 as Step
+            else:
+                from .train_engine import TrainStep as Step
+            loss, dev_out = Step.apply(self, x, targets, *self.parameters())
             return loss, dev_out.detach().cpu()
         if self.training:
-            from .train_engine import train_forward
+            if self.precision == "bf16":
+                from .train_engine_bf16 import train_forward_bf16 as fwd
+            else:
+                from .train_engine import train_forward as fwd
             with torch.no_grad():
-                _, dev_out, _ = train_forward(self, x, None)
+                _, dev_out, _ = fwd(self, x, None)
             return dev_out.detach().cpu()
         dev_out = self.forward_device(x)
         out = dev_out.detach().cpu()

@@ -5,7 +5,7 @@ from amyloid_yolo_paper_amd import cfg_gen, synth
 from amyloid_yolo_paper_amd.models import Darknet
 from amyloid_yolo_paper_amd.utils import weights_init_normal
 B, S = int(sys.argv[1]), int(sys.argv[2])
-m = Darknet(cfg_gen.write_cfg(3), precision='fp32').to('cuda'); m.apply(weights_init_normal); m.train()
+m = Darknet(cfg_gen.write_cfg(3), precision=(sys.argv[3] if len(sys.argv) > 3 else 'fp32')).to('cuda'); m.apply(weights_init_normal); m.train()
 x = torch.from_numpy(synth.synth_tiles(min(B, 4), S)).repeat((B + 3) // 4, 1, 1, 1)[:B].cuda()
 tg = torch.from_numpy(synth.synth_targets(B, 3, seed=3, grid=S // 8)).cuda()
 opt = torch.optim.Adam(m.parameters())

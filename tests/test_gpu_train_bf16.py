@@ -153,3 +153,67 @@ def test_bn_train_bf16_fwd_bwd_and_plumbing():
     d2 = to_blocked(bf(torch.ones(2, 32, 8, 8)), dev)
     check(L.ay_slice_accumulate_bf16(ptr(db1), ptr(d2), 2, 32, 48, 16, 8, 8, 0, 1, st))
     assert torch.equal(from_blocked(d2, 32), bf(dout[:, 16:] + 1.0))
+
+
+def test_bf16_train_step_tracks_fp32_step(tmp_cfg_dir):
+    """One training step on the bf16 MFMA path vs the fp32 reference-precision path (same model, weights, batch).
+
+    Every kernel of the bf16 path is pinned against autograd above; end to end the two paths cannot agree tightly below a
+    LeakyReLU: bf16 activations (relative noise 2^-9) put ~0.5-1 % of the pre-activations of every layer on the other
+    side of zero, where the slope differs 10x, so the gradients are evaluated at slightly different points of a
+    piecewise-linear function and decorrelate by ~0.3 % cosine per layer on the way down (measured: 0.9997 at the heads,
+    0.98-0.99 one block below, ~0.67 at layer 0 after 75 layers; scripts/dbg_train_bf16.py prints the whole profile).
+    Checked here: loss within 10 %, heads >= 0.995, the block under each head >= 0.92, everything else >= 0.5 and finite,
+    BN statistics close, and 8 Adam steps on a fixed batch reduce the loss on both paths to within 25 % of each other."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from amyloid_yolo_paper_amd import cfg_gen, parse_config, synth
+    from amyloid_yolo_paper_amd.models import Darknet
+    C_, S, B = 3, 256, 4
+    cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
+    defs = parse_config.parse_model_config(cfg)
+    wpath = os.path.join(tmp_cfg_dir, f"synth_c{C_}.weights")
+    if not os.path.exists(wpath):
+        synth.write_darknet_weights(wpath, defs, synth.synth_params(defs, seed=7), seen=0)
+    x = torch.from_numpy(synth.synth_tiles(B, S, 10))
+    tg = torch.from_numpy(synth.synth_targets(B, C_, seed=21, max_per_tile=6, min_per_tile=3, wh_range=(0.05, 0.4), grid=S // 8))
+    res = {}
+    for prec in ("fp32", "bf16"):
+        m = Darknet(cfg, precision=prec).to("cuda")
+        m.load_darknet_weights(wpath)
+        m.train()
+        loss, out = m(x, tg)
+        loss.backward()
+        grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+        stats = {n: b.detach().float().cpu() for n, b in m.named_buffers() if "running" in n}
+        first = float(loss.item())
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        opt.step()
+        opt.zero_grad()
+        for _ in range(7):
+            loss, _ = m(x, tg)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+        res[prec] = (first, grads, stats, out, float(loss.item()))
+    l32, g32, s32, o32, e32 = res["fp32"]
+    l16, g16, s16, o16, e16 = res["bf16"]
+    assert abs(l16 - l32) <= 0.10 * abs(l32), (l16, l32)
+    assert e32 < l32 and e16 < l16 and abs(e16 - e32) <= 0.25 * abs(e32), (l32, e32, l16, e16)   # both learn, alike
+
+    def cos(n):
+        a, b_ = g16[n].reshape(-1), g32[n].reshape(-1)
+        assert torch.isfinite(a).all(), n
+        return float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
+
+    for n in ("module_list.105.conv_105.weight", "module_list.93.conv_93.weight", "module_list.81.conv_81.weight"):
+        assert cos(n) >= 0.995, (n, cos(n))
+    for n in ("module_list.104.conv_104.weight", "module_list.92.conv_92.weight", "module_list.80.conv_80.weight"):
+        assert cos(n) >= 0.92, (n, cos(n))
+    for n in g32:
+        assert cos(n) >= 0.5, (n, cos(n))
+    for n in ("module_list.1.batch_norm_1.running_mean", "module_list.80.batch_norm_80.running_var"):
+        assert float((s16[n] - s32[n]).abs().max()) <= 0.03 * float(s32[n].abs().max()) + 1e-3, n
+    d = np.abs(o16.numpy()[..., 4:] - o32.numpy()[..., 4:])
+    assert np.quantile(d, 0.99) <= 0.1 and d.max() <= 0.8, (float(np.quantile(d, 0.99)), float(d.max()))   # gain-amplified objectness logits
