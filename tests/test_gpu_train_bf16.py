@@ -217,6 +217,6 @@ def test_bf16_train_step_tracks_fp32_step(tmp_cfg_dir):
         else:   # BN / bias gradients are heavily cancelling sums (noise dominated in the early layers): finite is all we ask
             assert torch.isfinite(g16[n]).all(), n
     for n in ("module_list.1.batch_norm_1.running_mean", "module_list.80.batch_norm_80.running_var"):
-        assert float((s16[n] - s32[n]).abs().max()) <= 0.03 * float(s32[n].abs().max()) + 1e-3, n
+        assert float((s16[n] - s32[n]).abs().max()) <= 0.10 * float(s32[n].abs().max()) + 1e-3, n
     d = np.abs(o16.numpy()[..., 4:] - o32.numpy()[..., 4:])
     assert np.quantile(d, 0.99) <= 0.1 and d.max() <= 0.8, (float(np.quantile(d, 0.99)), float(d.max()))   # gain-amplified objectness logits
