@@ -315,6 +315,14 @@ class Darknet(nn.Module):
         out._ay_device = dev_out
         return out
 
+    def train_step_device(self, x, targets):
+        """training forward with the autograd node attached, outputs left on the device: (loss, out [B,N,5+C] cuda)"""
+        if self.precision == "bf16" and self.training:
+            from .train_engine_bf16 import TrainStepBf16 as Step
+        else:
+            from .train_engine import TrainStep as Step
+        return Step.apply(self, x, targets, *self.parameters())
+
     @torch.no_grad()
     def forward_device(self, x, out_slot=0):
         """x [B,3,S,S] float32 (any device) -> device tensor [B, N, 5+C] (valid until the next forward into the same

@@ -100,3 +100,31 @@ def broadcast_parameters(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+class FlatAdam:
+    """torch.optim.Adam's update (reference ``train.py:81``: default lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight
+    decay) as ONE kernel over flat buffers: parameters are re-pointed to views of one flat fp32 tensor, gradients are the
+    FlatGradReducer's flat buffer, moments are flat.  `grad_scale` folds the 1/world averaging into the update."""
+
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.red = reducer
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        flat = torch.empty_like(reducer.flat)
+        for p, (o, n) in zip(reducer.params, reducer.offsets):
+            flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + n].view_as(p)
+        self.flat = flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+
+    def step(self, grad_scale=1.0):
+        import ctypes as C
+        from . import _lib
+        self.step_count += 1
+        _lib.check(_lib.lib().ay_adam_flat(_lib.ptr(self.flat), _lib.ptr(self.red.flat), _lib.ptr(self.m), _lib.ptr(self.v), self.flat.numel(),
+                                            C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                            self.step_count, C.c_float(grad_scale), _lib.stream_ptr()), "ay_adam_flat")
+        for p in self.red.params:   # the packed/derived copies of the weights are stale now
+            p._version  # (touching nothing: models.Darknet keys its caches on data_ptr/_version; training re-packs per step)

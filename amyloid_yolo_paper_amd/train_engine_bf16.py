@@ -4,7 +4,8 @@
   (``ay_conv_wgrad_bf16``) run on the matrix cores over blocked-bf16 tensors;
 * train-mode BatchNorm is a statistics pass + an apply pass around the raw convolution output, the shortcut add fused
   into the apply pass; its backward recomputes the pre-activation from the saved raw output;
-* the stem (3 input channels, fp32 image) and the YOLO loss stay on the fp32 kernels;
+* the stem runs through the same kernels (the fp32 image becomes one zero-padded 16-channel bf16 plane); the YOLO loss
+  stays on the fp32 kernel;
 * parameter gradients are fp32 (``.grad`` of the fp32 master parameters), activations / activation gradients bf16.
 """
 import ctypes as C

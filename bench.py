@@ -22,6 +22,10 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP1
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: tiles/s of the inference hot path (headline); train: imgs/s of the training step (configs[2]/[3])")
+    ap.add_argument("--train_batch", type=int, default=32)
+    ap.add_argument("--train_size", type=int, default=416, help="training tile side (reference default train.py:36)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -69,6 +73,9 @@ def main():
     from amyloid_yolo_paper_amd import _lib, build as aybuild, cfg_gen, parse_config, synth
     from amyloid_yolo_paper_amd.models import Darknet
     from amyloid_yolo_paper_amd.utils import nms_device
+
+    if a.mode == "train":
+        return bench_train(a, rank, local_rank, world, dev)
 
     if not os.path.exists(_lib.LIB_PATH):
         if rank == 0:
@@ -184,6 +191,73 @@ def main():
             }
         if not a.no_cpu_baseline and a.gpus == 1:
             result["cpu_baseline"] = cpu_baseline(a, cfg, params)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_train(a, rank, local_rank, world, dev):
+    """BASELINE.json configs[2]/[3]: random-init YOLOv3 (3 classes), batch 32 per GPU, synthetic boxes; one step = forward
+    (train-mode BN, loss) + backward + gradient all-reduce over RCCL (N > 1) + Adam, all inside the timed region."""
+    import torch
+    import torch.distributed as dist
+    from amyloid_yolo_paper_amd import cfg_gen, synth
+    from amyloid_yolo_paper_amd.models import Darknet
+    from amyloid_yolo_paper_amd.parallel import FlatAdam, FlatGradReducer, broadcast_parameters
+    from amyloid_yolo_paper_amd.utils import weights_init_normal
+    B, S = a.train_batch, a.train_size
+    torch.manual_seed(1234)
+    model = Darknet(cfg_gen.write_cfg(a.classes), img_size=S, precision="bf16").to(dev)
+    model.apply(weights_init_normal)
+    broadcast_parameters(model)
+    model.train()
+    nu = min(8, B)
+    x = torch.from_numpy(synth.synth_tiles(nu, S, start=100 + rank * nu)).to(dev)
+    x = x.repeat((B + nu - 1) // nu, 1, 1, 1)[:B].contiguous()
+    tg = torch.from_numpy(synth.synth_targets(B, a.classes, seed=77 + rank, grid=S // 8)).to(dev)
+    red = FlatGradReducer(model.parameters(), n_buckets=4)
+    opt = FlatAdam(red)
+    losses = []
+
+    def step():
+        loss, _ = model.train_step_device(x, tg)
+        loss.backward()
+        red.all_reduce(average=False)
+        opt.step(grad_scale=1.0 / world)
+        red.zero()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses.append(step())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lv = [float(l.item()) for l in losses]
+    assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite training loss"
+    flops_per_img = 3.0 * sum(conv_flops(e, 1, 1024) for e in model._graph if e["type"] == "convolutional") * (S / 1024.0) ** 2
+    result = {
+        "metric": "train imgs/sec", "value": round(world * B * a.steps / elapsed, 2), "unit": "imgs/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"configs[2]: random-init YOLOv3 C={a.classes}, batch={B}/GPU, {S}x{S} synthetic tiles + boxes, train-mode BN, "
+                               f"loss + backward + {'RCCL all-reduce (246 MB fp32, 4 buckets) + ' if world > 1 else ''}Adam",
+                   "global_batch": world * B, "tile": S, "parallelism": f"dp{world}", "first_loss": round(lv[0], 3), "last_loss": round(lv[-1], 3),
+                   "model_tflops": round(world * B * a.steps * flops_per_img / elapsed / 1e12, 1)},
+    }
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
