@@ -43,6 +43,22 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// 16-byte LDS-DMA (global_load_lds_dwordx4): lane l copies 16 B from its own `gsrc` to LDS byte address `lds_addr + 16*l`
+// (`lds_addr` wave-uniform).  Issued through inline asm so that hipcc neither counts it nor guards LDS reads against it:
+// with the builtin the compiler inserted `s_waitcnt vmcnt(0)` between a DMA and the next ds_read / MFMA whenever it could
+// not prove the buffers distinct (seen on the 3-deep 1x1 ring: every DMA was waited for on the spot, 6x slower).  The
+// caller owns the ordering: a counted `s_waitcnt vmcnt(N)` + barrier before anyone reads the data.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 static inline hipStream_t S(ay_stream_t s) { return (hipStream_t)s; }
 
 }  // namespace ay

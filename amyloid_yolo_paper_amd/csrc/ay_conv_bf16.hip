@@ -627,6 +627,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_zero_page);
+    const unsigned lds_base = lds_addr_of(lds);
 
     // ---- loader: piece i of this wave is global piece q = i*8 + wave ------------------------------------------
     // kind: pixel piece (kk, j) | filter piece (kk, j) | dummy.  Per lane: byte offset from the item's base, or -1.
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     int ld_item = item, ld_s = 0, ld_par = 0;
     bool ld_done = false;
     const float* ld_ss = nullptr;  // per-lane source of the scale/shift piece (nullptr: zero page)
-    auto setup_loader = [&](int it) {
+    auto setup_loader = [&](int it) __attribute__((always_inline)) {
         const int cg = it % a.n_cgroups;
         const int pt = it / a.n_cgroups;
         const int b = pt / tiles_per_img;
@@ -666,32 +667,30 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             src_off[i] = off;
         }
     };
-    auto issue_stage = [&](int buf) {  // DMA the loader's current stage into ring slot `buf`, then advance the loader
+    auto issue_piece = [&](int i, int buf) __attribute__((always_inline)) {  // DMA piece i of the loader's current stage into ring slot `buf`
         const uint8_t* sp = ld_src + (size_t)ld_s * NK * in_plane;
         const uint8_t* wp = ld_w + (size_t)ld_s * w_stage_stride;
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int q = i * 8 + wave;  // wave-uniform
-            const uint8_t* g;
-            int dst;
-            if (q < NK * PX_PIECES) {
-                const int kk = q / PX_PIECES, j = q % PX_PIECES;
-                g = sp + src_off[i];
-                dst = buf * BUF_BYTES + kk * PIX_SLAB + j * 1024;
-            } else if (q < NPIECE) {
-                g = wp + src_off[i];
-                dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
-            } else if (q == NPIECE) {
-                g = reinterpret_cast<const uint8_t*>(ld_ss);
-                dst = SS_BASE + ld_par * 1024;
-            } else {
-                g = zero_page;
-                dst = DUMMY_BASE;
-            }
-            if (q == NPIECE ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
+        const int q = i * 8 + wave;  // wave-uniform
+        const uint8_t* g;
+        int dst;
+        if (q < NK * PX_PIECES) {
+            const int kk = q / PX_PIECES, j = q % PX_PIECES;
+            g = sp + src_off[i];
+            dst = buf * BUF_BYTES + kk * PIX_SLAB + j * 1024;
+        } else if (q < NPIECE) {
+            g = wp + src_off[i];
+            dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
+        } else if (q == NPIECE) {
+            g = reinterpret_cast<const uint8_t*>(ld_ss);
+            dst = SS_BASE + ld_par * 1024;
+        } else {
+            g = zero_page;
+            dst = DUMMY_BASE;
         }
+        if (q == NPIECE ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
+        dma16(g, lds_base + __builtin_amdgcn_readfirstlane(dst));
+    };
+    auto advance_loader = [&]() __attribute__((always_inline)) {
         if (++ld_s == a.cin / (16 * NK)) {
             ld_s = 0;
             ld_par = (ld_par + 1) & 3;
@@ -701,6 +700,11 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             else
                 ld_done = true;
         }
+    };
+    auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) issue_piece(i, buf);
+        advance_loader();
     };
 
     int pb[NT];
@@ -755,20 +759,19 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         for (int s = 0; s < nstages; ++s) {
             const bool last_stage = (s + 1 == nstages);
             // stage g+NBUF-1 -> the slot that was read during stage g-1 (every wave passed the barrier since)
-            bool issued = false;
-            if (!ld_done) {
-                int slot_ld = cur + (NBUF - 1);
-                if (slot_ld >= NBUF) slot_ld -= NBUF;
-                issue_stage(slot_ld);
-                issued = true;
-            }
+            // the PW DMA pieces of stage g+NBUF-1 are issued one by one behind the MFMA groups of this stage (an LDS-DMA
+            // issue costs the wave 60-180 cycles; behind 4-8 queued MFMAs it is hidden, in a burst at the stage start
+            // both waves of a SIMD pay it at the same time)
+            const bool issued = !ld_done && !(a.dbg & 1);
+            int slot_ld = cur + (NBUF - 1);
+            if (slot_ld >= NBUF) slot_ld -= NBUF;
             constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
             if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
 
             const uint8_t* L = lds + cur * BUF_BYTES;
             constexpr int NSTEP = NK * KK2;
             bf16x8 af[2][MT], bfr[2][NT];
-            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) __attribute__((always_inline)) {
                 const int kk = t / KK2, tap = t % KK2;
                 const int kh = tap / KS, kw = tap % KS;
 #pragma unroll
@@ -778,9 +781,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 for (int n = 0; n < NT; ++n)
                     fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
             };
-            load_frags(0, af[0], bfr[0]);
+            if (!(a.dbg & 2)) load_frags(0, af[0], bfr[0]);
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {
+                if (a.dbg & 2) break;
                 if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
@@ -791,7 +795,13 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (issued) {
+#pragma unroll
+                    for (int i = 0; i < PW; ++i)  // constant trip count: src_off[] must stay in registers
+                        if (i >= t * PW / NSTEP && i < (t + 1) * PW / NSTEP) issue_piece(i, slot_ld);
+                }
             }
+            if (issued) advance_loader();
             // stage g+1 must have landed before anyone reads it: everything but the stage(s) issued after it
             if (!(last_stage && !has_next)) {
                 if constexpr (NBUF == 3) {
