@@ -578,6 +578,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, i
 //   * every wave issues the same number PW of 1-KiB DMA pieces per stage (the piece list is padded with dummy
 //     pieces that copy zeros into a scratch KiB), so "stage g+1 has landed" is one constant `s_waitcnt vmcnt(PW)`.
 __device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];  // zero-initialised by the loader
+// AY_DBG&8: phase clock of the ring kernel, summed over workgroups (wave 0): [0] stage loops, [1] epilogues, [2] items,
+// [3] workgroups, [4] whole-kernel ticks per workgroup; 100 MHz ticks (s_memrealtime)
+__device__ unsigned long long g_phase_ticks[8];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
@@ -739,7 +742,11 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
 
     int cur = 0;  // ring slot of the stage the MFMAs read
     int par = 0;  // scale/shift region of the item the MFMAs work on
+    const bool clk = (a.dbg & 8) && tid == 0;
+    unsigned long long tk_stage = 0, tk_epi = 0, tk_items = 0, tk0 = 0, tk_begin = 0;
+    if (clk) tk_begin = wall_clock64();
     while (true) {
+        if (clk) tk0 = wall_clock64();
         const int cg = item % a.n_cgroups;
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
@@ -817,11 +824,27 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             }
             if (++cur == NBUF) cur = 0;
         }
+        if (clk) {
+            const unsigned long long t = wall_clock64();
+            tk_stage += t - tk0;
+            tk0 = t;
+        }
         conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4)>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                        reinterpret_cast<const float*>(lds + SS_BASE + par * 1024));
+        if (clk) {
+            tk_epi += wall_clock64() - tk0;
+            ++tk_items;
+        }
         if (!has_next) break;
         item = next_item;
         par = (par + 1) & 3;
+    }
+    if (clk) {
+        atomicAdd(&g_phase_ticks[0], tk_stage);
+        atomicAdd(&g_phase_ticks[1], tk_epi);
+        atomicAdd(&g_phase_ticks[2], tk_items);
+        atomicAdd(&g_phase_ticks[3], 1ull);
+        atomicAdd(&g_phase_ticks[4], wall_clock64() - tk_begin);
     }
 }
 
@@ -845,6 +868,7 @@ int conv_num_cus() {
         hipDeviceProp_t p;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n < 8) n = 256;
+        if (getenv("AY_CUS")) n = atoi(getenv("AY_CUS"));  // timing experiments only
         n -= n % 8;
     }
     return n;
@@ -916,6 +940,17 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
     }
     AY_CHECK_LAUNCH("conv_bf16_kernel");
+    if (V2 && (dbg & 8) && conv_mode() >= 4) {  // timing experiments only: synchronous phase report per launch
+        unsigned long long t[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
+        if (t[3])
+            fprintf(stderr, "[ay phase] k%d s%d BN%d tile%dx%d cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us, epilogue %.2f us; wg total %.1f us\n",
+                    KS, STRIDE, BN, TH, TW, d->cin, d->cout, d->hout, residual ? 1 : 0, (double)t[2] / t[3], t[0] * 0.01 / t[2],
+                    t[1] * 0.01 / t[2], t[4] * 0.01 / t[3]);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
+    }
     return AY_OK;
 }
 

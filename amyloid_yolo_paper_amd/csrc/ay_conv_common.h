@@ -23,10 +23,12 @@ struct ConvArgs {
 // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // A lane pair (c, c+32) holds 8 consecutive channels of pixel c per register-quad; one
 // v_permlane32_swap per dword turns two quads into two full 16-byte stores (1 KiB per wave store).
-// residual operand of one wave tile, in the accumulator's own layout: [m][n][quad pair][quad] x 8 bytes
+// residual operand of one wave tile, in the STORE layout (lane (c, hh) holds the 16 bytes it will store to: channels
+// 8hh..8hh+7 of its pixel, one coalesced 16-byte load); the same two permlane32 swaps that turn accumulator quads into
+// store vectors are their own inverse and bring it back to the accumulator layout before the fp32 add.
 template <int MT, int NT>
 struct ResRegs {
-    uint2 r[MT][NT][2][2];
+    uint4 r[MT][NT][2];
 };
 
 template <int BN, int MT, int NT, int TW, bool HAS_RES>
@@ -39,8 +41,10 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int p = (wn * NT + n) * 32 + c;
-            const int oy = y0 + p / TW, ox = x0 + p % TW;
-            const bool ok = (oy < a.hout) && (ox < a.wout);
+            // clamped pixel: an always-valid address, so the loads are unconditional (a load under `if (ok)`, or an address
+            // select the compiler turns into a branch, is waited for on the spot and serialises the residual stream);
+            // pixels outside the image are never stored
+            const int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1);
             const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -48,14 +52,7 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
                 for (int qp = 0; qp < 2; ++qp) {
                     const int ch0 = cbase + m * 32 + qp * 16;
                     const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
-                    uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
-                    if (ok) {
-                        const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                        v0 = *reinterpret_cast<const uint2*>(rp);
-                        v1 = *reinterpret_cast<const uint2*>(rp + 16);
-                    }
-                    rr.r[m][n][qp][0] = v0;
-                    rr.r[m][n][qp][1] = v1;
+                    rr.r[m][n][qp] = *reinterpret_cast<const uint4*>(a.residual + (plane * out_plane_px + pix) * 32 + hh * 16);
                 }
         }
     }
@@ -72,27 +69,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const int cbase = cg * BN + wm * MT * 32;
     const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
 
-    uint2 rres[2][2][2];  // [ping/pong][quad pair][quad]: residual of one (n, m) 32x32 block, loaded one block ahead
-    auto load_res = [&](int t, uint2 (&r)[2][2]) {
+    // residual of (n, m) 32x32 blocks, loaded RD blocks ahead of their use: a load issued only one block (~150 cycles)
+    // ahead exposes nearly the whole memory latency on every block; the MFMA fragment registers are dead here, so the
+    // deeper ring costs no extra registers
+    constexpr int RD = (MT * NT >= 4) ? 2 : MT * NT;
+    uint4 rres[RD][2];
+    auto load_res = [&](int t, uint4 (&r)[2]) __attribute__((always_inline)) {
         const int n = t / MT, m = t % MT;
         const int p = (wn * NT + n) * 32 + c;
-        const int oy = y0 + p / TW, ox = x0 + p % TW;
-        const bool ok = (oy < a.hout) && (ox < a.wout);
+        const int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1);  // clamped: see residual_prefetch
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             const size_t plane = (size_t)b * (CP / 16) + ((cbase + m * 32 + qp * 16) >> 4);
-            uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
-            if (ok) {
-                const uint8_t* rp = a.residual + (plane * out_plane_px + pix) * 32 + hh * 8;
-                v0 = *reinterpret_cast<const uint2*>(rp);
-                v1 = *reinterpret_cast<const uint2*>(rp + 16);
-            }
-            r[qp][0] = v0;
-            r[qp][1] = v1;
+            r[qp] = *reinterpret_cast<const uint4*>(a.residual + (plane * out_plane_px + pix) * 32 + hh * 16);
         }
     };
-    if constexpr (HAS_RES && RES_INLINE) load_res(0, rres[0]);
+    if constexpr (HAS_RES && RES_INLINE) {
+#pragma unroll
+        for (int t = 0; t < RD; ++t) load_res(t, rres[t]);
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
@@ -101,8 +97,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            uint4 rcur[2];
             if constexpr (HAS_RES && RES_INLINE) {
-                if (n * MT + m + 1 < NT * MT) load_res(n * MT + m + 1, rres[(n * MT + m + 1) & 1]);
+                rcur[0] = rres[(n * MT + m) % RD][0];
+                rcur[1] = rres[(n * MT + m) % RD][1];
+                if (n * MT + m + RD < NT * MT) load_res(n * MT + m + RD, rres[(n * MT + m) % RD]);
             }
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
@@ -147,15 +146,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 } else {
                     const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
                     if constexpr (HAS_RES) {
-                        // residual (in the accumulator's own layout) added in fp32 before the single bf16 rounding
-                        uint2 r0v, r1v;
-                        if constexpr (RES_INLINE) {
-                            r0v = rres[(n * MT + m) & 1][qp][0];
-                            r1v = rres[(n * MT + m) & 1][qp][1];
-                        } else {
-                            r0v = rr.r[m][n][qp][0];
-                            r1v = rr.r[m][n][qp][1];
-                        }
+                        // residual: store layout -> accumulator layout, added in fp32 before the single bf16 rounding
+                        uint4 rv;
+                        if constexpr (RES_INLINE)
+                            rv = rcur[qp];
+                        else
+                            rv = rr.r[m][n][qp];
+                        auto sx = __builtin_amdgcn_permlane32_swap(rv.x, rv.z, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(rv.y, rv.w, false, false);
+                        const uint2 r0v = make_uint2(sx[0], sy[0]), r1v = make_uint2(sx[1], sy[1]);
                         v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
                         v[1] += bf2f((uint16_t)(r0v.x >> 16));
                         v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));

@@ -23,22 +23,25 @@ struct StemFusedArgs {
     ConvArgs c1;            // layer 1 as a ConvArgs (src unused)
 };
 
-__global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, int n_items) {
+// 16 waves: every phase is a chain of dependent LDS round trips per wave, so more (shorter) chains per CU, not wider ones
+__global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, int n_items) {
     constexpr int TH = 8, TW = 32, BN = 64;
     constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 17 x 65 stem pixels feed the tile
     constexpr int S_PIX = SH * SW;                        // 1105
     constexpr int S_PIXP = 1120;                          // padded to 35 blocks of 32
     constexpr int IH = SH + 2, IW = SW + 2;               // 19 x 67 image pixels
     constexpr int IMG_ELEMS = 3 * IH * IW;                // 3819
-    constexpr int NIMG = (IMG_ELEMS + 511) / 512;         // 8 prefetch registers per thread
+    constexpr int NT_ = 1024;                                // threads
+    constexpr int NIMG = (IMG_ELEMS + NT_ - 1) / NT_;     // 4 prefetch registers per thread
     constexpr int SLAB = 2 * S_PIXP * 16;                 // one 16-channel chunk of stem output
     constexpr int W1_BYTES = 2 * 9 * 2 * BN * 16;         // 36864
     constexpr int OFF_IMG = 0;
     constexpr int OFF_STEM = ((IMG_ELEMS * 4 + 15) / 16) * 16;
     constexpr int OFF_W1 = OFF_STEM + 2 * SLAB;
-    constexpr int LDS_BYTES = OFF_W1 + W1_BYTES;
+    constexpr int OFF_SS0 = OFF_W1 + W1_BYTES;
+    constexpr int LDS_BYTES = OFF_SS0 + 256;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    constexpr int MT = 2, NT = 1;
+    constexpr int MT = 1, NT = 1;                         // wave tile 32 channels x 32 pixels: waves = 2 (channels) x 8 (rows)
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     float* img = reinterpret_cast<float*>(lds + OFF_IMG);
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
     // layer-1 filters: resident for the whole kernel
-    for (int u = tid; u < W1_BYTES / 16; u += 512)
+    for (int u = tid; u < W1_BYTES / 16; u += NT_)
         *reinterpret_cast<uint4*>(lds + OFF_W1 + u * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.w) + (size_t)u * 16);
     // stem filters as the MFMA A operand: lane (row co = c, half hh), k-step ks: k = 16*ks + 8*hh + j
     bf16x8 wa[2];
@@ -74,14 +77,12 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
             const int k = 16 * ks + 8 * hh + e;
             koff[ks][e] = k < 27 ? ((k / 9) * IH + (k % 9) / 3) * IW + k % 3 : -1;
         }
-    float sc0[4][4], sh0[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc0[q][j] = s.scale0[8 * q + 4 * hh + j];
-            sh0[q][j] = s.shift0[8 * q + 4 * hh + j];
-        }
+    // stem scale/shift: [scale 32][shift 32] floats in LDS (32 registers otherwise; 16 waves leave 128 per lane)
+    float* ss0 = reinterpret_cast<float*>(lds + OFF_SS0);
+    if (tid < 32) {
+        ss0[tid] = s.scale0[tid];
+        ss0[32 + tid] = s.shift0[tid];
+    }
 
     float rimg[NIMG];
     auto load_image = [&](int it) {
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
         const float* xb = s.x + (size_t)b * 3 * s.H * s.W;
 #pragma unroll
         for (int i = 0; i < NIMG; ++i) {
-            const int u = i * 512 + tid;
+            const int u = i * NT_ + tid;
             float v = 0.f;
             if (u < IMG_ELEMS) {
                 const int col = u % IW, r = (u / IW) % IH, ci = u / (IW * IH);
@@ -103,9 +104,9 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
     };
 
     // layer-1 fragment addresses (same maps as conv_bf16_ring_kernel with STRIDE 2, NT = 1, WM = 1, WN = 8)
-    const int wn = wave;
+    const int wn = wave & 7, wm = wave >> 3;
     const int pb = (hh * S_PIXP + (wn * 2) * SW + c * 2) * 16;  // pixel (ty = wn, tx = c) -> stem pixel (2ty, 2tx)
-    const int wa1 = OFF_W1 + (hh * BN + c) * 16;
+    const int wa1 = OFF_W1 + (hh * BN + wm * 32 + c) * 16;
 
     load_image(item);
     while (true) {
@@ -118,14 +119,14 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
         // ---- A: image tile -> LDS ----------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < NIMG; ++i) {
-            const int u = i * 512 + tid;
+            const int u = i * NT_ + tid;
             if (u < IMG_ELEMS) img[u] = rimg[i];
         }
         __syncthreads();
         if (has_next) load_image(next_item);  // in flight during B, C, D
 
         // ---- B: stem by MFMA into the slabs ----------------------------------------------------------------
-        for (int blk = wave; blk < S_PIXP / 32; blk += 8) {
+        for (int blk = wave; blk < S_PIXP / 32; blk += 16) {
             const int P = blk * 32 + c;
             const int sy = P / SW, sx = P % SW;  // stem pixel inside the halo tile (P >= S_PIX: padding rows of the slab)
             const bool inside = P < S_PIX;
@@ -153,9 +154,12 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float o[4];
+                const float4 scv = *reinterpret_cast<const float4*>(ss0 + 8 * q + 4 * hh);
+                const float4 shv = *reinterpret_cast<const float4*>(ss0 + 32 + 8 * q + 4 * hh);
+                const float sc0q[4] = {scv.x, scv.y, scv.z, scv.w}, sh0q[4] = {shv.x, shv.y, shv.z, shv.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[4 * q + j] * sc0[q][j] + sh0[q][j];
+                    float t = acc[4 * q + j] * sc0q[j] + sh0q[j];
                     if (s.leaky0) t = t > 0.f ? t : 0.1f * t;
                     o[j] = real ? t : 0.f;
                 }
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(512, 2) stem_s2_fused_kernel(StemFusedArgs s, 
         }
         // ---- D: epilogue ----------------------------------------------------------------------------------
         ResRegs<MT, NT> rr;
-        conv_epilogue<BN, MT, NT, TW, false, false>(a, acc1, rr, b, 0, 0, wn, c, hh, y0, x0);
+        conv_epilogue<BN, MT, NT, TW, false, false>(a, acc1, rr, b, 0, wm, wn, c, hh, y0, x0);
         if (!has_next) break;
         __syncthreads();  // everyone is done reading the slabs / image before the next item overwrites them
         item = next_item;
@@ -236,7 +240,7 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     const int per_xcd = (int)((n_items + 7) / 8);
     const int cu_slots = conv_num_cus() / 8;
     dim3 grid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
-    hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(512), 0, S(stream), s, (int)n_items);
+    hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
     AY_CHECK_LAUNCH("stem_s2_fused_kernel");
     return AY_OK;
 }
