@@ -365,6 +365,51 @@ __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __re
     }
 }
 
+// utils/utils.py:276-330 as dense tensors: everything the 10-tuple holds, from the pass-1 cell state (obj / noobj flags,
+// last-writer target index, multi-hot classes).  pred_boxes [B,A,G,G,4] (cxcywh, grid units), pred_cls [B,A,G,G,C].
+__global__ void build_targets_dense(const float* __restrict__ pred_boxes, const float* __restrict__ pred_cls,
+                                    const float* __restrict__ tgt, YoloGeom g, const int* __restrict__ winner,
+                                    const unsigned* __restrict__ flags, float* __restrict__ iou_scores,
+                                    float* __restrict__ class_mask, uint8_t* __restrict__ obj_mask, uint8_t* __restrict__ noobj_mask,
+                                    float* __restrict__ tx, float* __restrict__ ty, float* __restrict__ tw, float* __restrict__ th,
+                                    float* __restrict__ tconf) {
+    const int cells = g.B * g.A * g.G * g.G;
+    for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += gridDim.x * blockDim.x) {
+        const int a = (cell / (g.G * g.G)) % g.A;
+        const unsigned f = flags[cell];
+        const bool obj = f & 1u;
+        float vx = 0.f, vy = 0.f, vw = 0.f, vh = 0.f, cm = 0.f, iou = 0.f;
+        if (obj) {
+            const float* r = tgt + (size_t)winner[cell] * 6;
+            const float gx = r[2] * g.G, gy = r[3] * g.G, gw = r[4] * g.G, gh = r[5] * g.G;
+            vx = gx - floorf(gx);
+            vy = gy - floorf(gy);
+            vw = logf(gw / g.aw[a] + 1e-16f);
+            vh = logf(gh / g.ah[a] + 1e-16f);
+            const float* pc = pred_cls + (size_t)cell * g.C;
+            float best = pc[0];
+            int arg = 0;
+            for (int k = 1; k < g.C; ++k)
+                if (pc[k] > best) {  // first maximum wins, like argmax
+                    best = pc[k];
+                    arg = k;
+                }
+            cm = (arg == (int)r[1]) ? 1.f : 0.f;
+            const float* pb = pred_boxes + (size_t)cell * 4;
+            iou = iou_cxcywh_p1(pb[0], pb[1], pb[2], pb[3], gx, gy, gw, gh);
+        }
+        iou_scores[cell] = iou;
+        class_mask[cell] = cm;
+        obj_mask[cell] = obj ? 1 : 0;
+        noobj_mask[cell] = (f & 2u) ? 0 : 1;
+        tx[cell] = vx;
+        ty[cell] = vy;
+        tw[cell] = vw;
+        th[cell] = vh;
+        tconf[cell] = obj ? 1.f : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m, float* __restrict__ v, size_t n,
                             float lr, float b1, float b2, float eps, float bc1, float bc2, float grad_scale) {
@@ -518,6 +563,53 @@ extern "C" int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets
         set_error("ay_yolo_loss_fwd_bwd: copy failed");
         return AY_ERR_LAUNCH;
     }
+    return AY_OK;
+}
+
+extern "C" size_t ay_build_targets_workspace_bytes(int batch, int num_anchors, int grid) {
+    return (size_t)batch * num_anchors * grid * grid * 8;  // winner + flags
+}
+
+extern "C" int ay_build_targets(const float* pred_boxes, const float* pred_cls, const float* targets, int n_targets, int batch,
+                                int num_anchors, int num_classes, int grid, const float* anchors_grid, float ignore_thres,
+                                float* iou_scores, float* class_mask, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty,
+                                float* tw, float* th, float* tcls, float* tconf, void* workspace, size_t workspace_bytes,
+                                ay_stream_t stream) {
+    AY_CHECK_ARG(pred_boxes && pred_cls && anchors_grid && iou_scores && class_mask && obj_mask && noobj_mask && tx && ty && tw && th &&
+                     tcls && tconf && workspace,
+                 "ay_build_targets: null");
+    AY_CHECK_ARG(num_anchors > 0 && num_anchors <= 8 && num_classes >= 1 && grid > 0 && batch > 0, "ay_build_targets: bad shape");
+    AY_CHECK_ARG(n_targets == 0 || targets, "ay_build_targets: targets null");
+    if (workspace_bytes < ay_build_targets_workspace_bytes(batch, num_anchors, grid)) {
+        set_error("ay_build_targets: workspace too small");
+        return AY_ERR_WORKSPACE;
+    }
+    hipStream_t st = S(stream);
+    YoloGeom g;
+    g.B = batch;
+    g.A = num_anchors;
+    g.C = num_classes;
+    g.G = grid;
+    for (int a = 0; a < num_anchors; ++a) {  // already in grid units (models.py:123), as the reference passes them
+        g.aw[a] = anchors_grid[2 * a];
+        g.ah[a] = anchors_grid[2 * a + 1];
+    }
+    const size_t cells = (size_t)batch * num_anchors * grid * grid;
+    int* winner = (int*)workspace;
+    unsigned* flags = (unsigned*)(winner + cells);
+    if (hipMemsetAsync(winner, 0xff, cells * 4, st) != hipSuccess || hipMemsetAsync(flags, 0, cells * 4, st) != hipSuccess ||
+        hipMemsetAsync(tcls, 0, cells * num_classes * 4, st) != hipSuccess) {
+        set_error("ay_build_targets: memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    if (n_targets > 0) {
+        hipLaunchKernelGGL(yolo_targets_pass1, dim3((n_targets + 255) / 256), dim3(256), 0, st, targets, n_targets, g, ignore_thres, winner,
+                           flags, tcls);
+        AY_CHECK_LAUNCH("yolo_targets_pass1");
+    }
+    hipLaunchKernelGGL(build_targets_dense, dim3(gridn(cells)), dim3(256), 0, st, pred_boxes, pred_cls, targets, g, winner, flags,
+                       iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tconf);
+    AY_CHECK_LAUNCH("build_targets_dense");
     return AY_OK;
 }
 

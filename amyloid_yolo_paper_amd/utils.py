@@ -96,6 +96,36 @@ def bbox_wh_iou(wh1, wh2):
     return inter / ((w1 * h1 + 1e-16) + w2 * h2 - inter)
 
 
+def build_targets(pred_boxes, pred_cls, target, anchors, ignore_thres):
+    """Reference ``utils/utils.py:276-330`` on the device: same arguments, same 10-tuple in the same order
+    ``(iou_scores, class_mask, obj_mask, noobj_mask, tx, ty, tw, th, tcls, tconf)``; masks are bool tensors.
+    ``pred_boxes`` [B,A,G,G,4] (cxcywh, grid units), ``pred_cls`` [B,A,G,G,C], ``target`` [nT,6],
+    ``anchors`` [A,2] already divided by the stride.  Results live on the device of ``pred_boxes``."""
+    L = _lib.lib()
+    pb = _to_dev(pred_boxes.detach()).to(torch.float32).contiguous()
+    pc = _to_dev(pred_cls.detach()).to(torch.float32).contiguous()
+    tg = _to_dev(target).to(torch.float32).contiguous()
+    B, A, G = pb.shape[0], pb.shape[1], pb.shape[2]
+    Cn = pc.shape[-1]
+    dev = pb.device
+    anc = torch.as_tensor(anchors, dtype=torch.float32).detach().cpu().contiguous().reshape(-1)
+    anc_c = (C.c_float * anc.numel())(*anc.tolist())
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+    iou_scores, class_mask, tx, ty, tw, th, tconf = (f(B, A, G, G) for _ in range(7))
+    tcls = f(B, A, G, G, Cn)
+    obj = torch.empty(B, A, G, G, device=dev, dtype=torch.uint8)
+    noobj = torch.empty(B, A, G, G, device=dev, dtype=torch.uint8)
+    nbytes = L.ay_build_targets_workspace_bytes(B, A, G)
+    ws = torch.empty(max(nbytes, 1), device=dev, dtype=torch.uint8)
+    nT = tg.shape[0]
+    check(L.ay_build_targets(ptr(pb), ptr(pc), ptr(tg) if nT else None, nT, B, A, Cn, G, anc_c, C.c_float(ignore_thres),
+                             ptr(iou_scores), ptr(class_mask), ptr(obj), ptr(noobj), ptr(tx), ptr(ty), ptr(tw), ptr(th), ptr(tcls),
+                             ptr(tconf), ptr(ws), ws.numel(), _lib.stream_ptr()), "ay_build_targets")
+    out_dev = pred_boxes.device
+    res = (iou_scores, class_mask, obj.bool(), noobj.bool(), tx, ty, tw, th, tcls, tconf)
+    return tuple(t.to(out_dev) for t in res)
+
+
 class NmsResult(list):
     """list of ``Tensor[n,7] | None`` (the reference's return value) that also carries, per image, the original
     row index of every emitted cluster head (``keep_idx``) and the candidate count after the conf filter."""

@@ -170,6 +170,16 @@ int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_tar
                          int num_classes, int grid, int img_dim, const float* anchors_wh /* host */, float ignore_thres,
                          float grad_scale, float* dhead, float* sums_out, void* workspace, size_t workspace_bytes,
                          ay_stream_t stream);
+/* utils/utils.py:276-330 build_targets on device, as the dense 10-tuple the reference returns (same order):
+ * pred_boxes [B,A,G,G,4] cxcywh in grid units, pred_cls [B,A,G,G,C], targets [nT,6] (sample, class, cx, cy, w, h in [0,1]),
+ * anchors_grid (HOST) [A,2] = anchors / stride (models.py:123).  Masks are bytes (0/1).  Duplicate (sample, anchor, cell)
+ * targets: the last one in target order wins, classes accumulate (multi-hot), as on the reference's CPU path. */
+size_t ay_build_targets_workspace_bytes(int batch, int num_anchors, int grid);
+int ay_build_targets(const float* pred_boxes, const float* pred_cls, const float* targets, int n_targets, int batch,
+                     int num_anchors, int num_classes, int grid, const float* anchors_grid /* host */, float ignore_thres,
+                     float* iou_scores, float* class_mask, uint8_t* obj_mask, uint8_t* noobj_mask, float* tx, float* ty,
+                     float* tw, float* th, float* tcls, float* tconf, void* workspace, size_t workspace_bytes,
+                     ay_stream_t stream);
 /* torch.optim.Adam step (train.py:81,118) on one flat buffer; grads are multiplied by grad_scale first (1/world size) */
 int ay_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, ay_stream_t stream);

@@ -259,3 +259,53 @@ def test_train_loop_checkpoint_and_eval(tmp_path, tmp_cfg_dir):
     m2.load_state_dict(ck)
     res = evaluate(m2, str(tmp_path / "valid.txt"), 0.5, 0.001, 0.5, 96, 2)   # API contract: tuple of 5 or None
     assert res is None or len(res) == 5
+
+
+_BT_NAMES = ["iou_scores", "class_mask", "obj_mask", "noobj_mask", "tx", "ty", "tw", "th", "tcls", "tconf"]
+
+
+@pytest.mark.parametrize("case", gc.TRAIN_CASES, ids=lambda c: c[0])
+def test_build_targets_device_vs_golden(golden_dir, case):
+    """utils.build_targets (ay_build_targets) against the reference's own outputs (tests/golden/bt_*.npz): masks exact,
+    floats within 1e-6 relative."""
+    from amyloid_yolo_paper_amd import utils as U
+    name, Cc, S, B, seed = case
+    z = np.load(os.path.join(golden_dir, "bt_" + name + ".npz"))
+    G = S // 8
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    pb = rng.uniform(0, G, (B, 3, G, G, 4)).astype(np.float32)
+    pc = rng.uniform(0, 1, (B, 3, G, G, Cc)).astype(np.float32)
+    tg = gc.train_targets(B, Cc, S, seed)
+    out = U.build_targets(torch.from_numpy(pb), torch.from_numpy(pc), torch.from_numpy(tg), torch.from_numpy(z["anchors"]), 0.5)
+    assert len(out) == 10
+    for n, v in zip(_BT_NAMES, out):
+        v = v.numpy()
+        if n in ("obj_mask", "noobj_mask"):
+            assert v.dtype == bool
+            np.testing.assert_array_equal(v, z[n])
+        else:
+            np.testing.assert_allclose(v, z[n], rtol=1e-6, atol=1e-6)
+
+
+def test_build_targets_device_duplicates_and_empty():
+    """duplicate (sample, anchor, cell) targets: last writer wins, classes accumulate; no targets: all-zero / all-noobj."""
+    from amyloid_yolo_paper_amd import utils as U
+    B, A, Cc, G = 3, 3, 3, 8
+    rng = np.random.Generator(np.random.PCG64(9))
+    pb = rng.uniform(0, G, (B, A, G, G, 4)).astype(np.float32)
+    pc = rng.uniform(0, 1, (B, A, G, G, Cc)).astype(np.float32)
+    tg = np.array([[0, 1, .31, .33, .3, .4], [0, 2, .32, .34, .31, .39], [1, 0, .7, .2, .1, .15], [1, 2, .71, .21, .6, .7],
+                   [2, 1, .5, .5, .9, .9], [2, 1, .12, .88, .05, .07], [0, 0, .9, .9, .2, .2]], np.float32)
+    anc = (np.array([(10, 13), (16, 30), (33, 23)], np.float32) / 8.0).astype(np.float32)
+    ref = bo.build_targets(pb, pc, tg, anc, 0.5)
+    out = U.build_targets(torch.from_numpy(pb).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(tg).cuda(), torch.from_numpy(anc), 0.5)
+    for n, v, r in zip(_BT_NAMES, out, ref):
+        assert v.is_cuda
+        v = v.cpu().numpy()
+        if r.dtype == bool:
+            np.testing.assert_array_equal(v, r, err_msg=n)
+        else:
+            np.testing.assert_allclose(v, r, rtol=1e-6, atol=1e-6, err_msg=n)
+    assert out[8].cpu().numpy().sum(-1).max() == 2.0  # a multi-hot cell exists in this case
+    out = U.build_targets(torch.from_numpy(pb), torch.from_numpy(pc), torch.zeros(0, 6), torch.from_numpy(anc), 0.5)
+    assert not out[2].any() and out[3].all() and all(float(out[i].abs().sum()) == 0.0 for i in (0, 1, 4, 5, 6, 7, 8, 9))
