@@ -27,6 +27,28 @@ def resize(image, size):
     return F.interpolate(image.unsqueeze(0), size=size, mode="nearest").squeeze(0)
 
 
+def ingest_tiles_device(tiles_u8, img_size, pad_value=0.0, out=None):
+    """uint8 HWC tiles [B,H,W,3] (NumPy or tensor, host or device) -> float32 [B,3,S,S] on the current HIP device:
+    ``to_tensor`` + ``pad_to_square`` + ``resize`` of this module (the reference's DEFAULT_TRANSFORMS + Resize image path)
+    in ONE device pass (``ay_ingest_tiles_u8``); the host uploads 3 bytes per pixel.  No CPU fallback."""
+    from . import _lib
+    from ._lib import check, ptr
+    if not torch.cuda.is_available():
+        raise _lib.AyError("no HIP device: ingest_tiles_device has no CPU fallback (use to_tensor/pad_to_square/resize on the host)")
+    t = torch.as_tensor(tiles_u8)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    assert t.dtype == torch.uint8 and t.dim() == 4 and t.shape[-1] == 3, "uint8 [B,H,W,3] tiles"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = t.to(dev, non_blocking=True).contiguous()
+    B, H, W, _ = t.shape
+    if out is None:
+        out = torch.empty(B, 3, img_size, img_size, device=dev, dtype=torch.float32)
+    assert out.shape == (B, 3, img_size, img_size) and out.is_contiguous() and out.dtype == torch.float32
+    check(_lib.lib().ay_ingest_tiles_u8(ptr(t), B, H, W, img_size, float(pad_value), ptr(out), _lib.stream_ptr()), "ay_ingest_tiles_u8")
+    return out
+
+
 def to_tensor(img_u8):
     """HWC uint8 -> CHW float32 /255 (what torchvision's ToTensor does)"""
     return torch.from_numpy(np.ascontiguousarray(img_u8.transpose(2, 0, 1))).float().div(255.0)
@@ -55,13 +77,16 @@ def default_transform(img_u8, boxes):
 class ImageFolder(Dataset):
     """sorted glob of a folder -> (path, tensor [3,S,S]) (reference ``utils/datasets.py:40-62`` + Resize)"""
 
-    def __init__(self, folder_path, img_size=416):
+    def __init__(self, folder_path, img_size=416, raw_u8=False):
         self.files = sorted(glob.glob("%s/*.*" % folder_path))
         self.img_size = img_size
+        self.raw_u8 = raw_u8  # hand out the decoded uint8 HWC tile; ``ingest_tiles_device`` does the rest on the GPU
 
     def __getitem__(self, index):
         path = self.files[index % len(self.files)]
         img = np.array(Image.open(path).convert("RGB"), dtype=np.uint8)
+        if self.raw_u8:
+            return path, torch.from_numpy(img)
         img, _ = default_transform(img, np.zeros((0, 5)))
         return path, resize(img, self.img_size)
 

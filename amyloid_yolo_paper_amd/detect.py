@@ -11,25 +11,36 @@ import torch
 from PIL import Image
 from torch.utils.data import DataLoader
 
-from .datasets import ImageFolder
+from .datasets import ImageFolder, ingest_tiles_device
 from .models import Darknet
 from .utils import load_classes, non_max_suppression, rescale_boxes
 
 
 def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_path="weights/yolov3.weights",
            class_path=None, conf_thres=0.8, nms_thres=0.4, batch_size=1, n_cpu=0, img_size=416, precision="bf16",
-           rescale=True, verbose=True):
+           rescale=True, verbose=True, device_ingest=True):
+    """``device_ingest``: upload the decoded uint8 tiles and do /255 + pad-to-square + nearest resize on the GPU
+    (``ay_ingest_tiles_u8``, bit-identical to the host transforms); batches of mixed image sizes are ingested one size at a time."""
     model = Darknet(model_def, img_size=img_size, precision=precision).to("cuda")
     if weights_path.endswith(".weights"):
         model.load_darknet_weights(weights_path)
     else:
         model.load_state_dict(torch.load(weights_path))
     model.eval()
-    loader = DataLoader(ImageFolder(image_folder, img_size=img_size), batch_size=batch_size, shuffle=False, num_workers=n_cpu)
+    loader = DataLoader(ImageFolder(image_folder, img_size=img_size, raw_u8=device_ingest), batch_size=batch_size, shuffle=False,
+                        num_workers=n_cpu, collate_fn=(lambda b: tuple(zip(*b))) if device_ingest else None)
     classes = load_classes(class_path) if class_path else None
     paths, results = [], []
     prev = time.time()
     for batch_i, (img_paths, imgs) in enumerate(loader):
+        if device_ingest:  # list of uint8 [H,W,3] tiles -> [B,3,S,S] on the device, grouped by source size
+            out = torch.empty(len(imgs), 3, img_size, img_size, device="cuda", dtype=torch.float32)
+            by_shape = {}
+            for i, t in enumerate(imgs):
+                by_shape.setdefault(tuple(t.shape), []).append(i)
+            for idx in by_shape.values():
+                out[idx] = ingest_tiles_device(torch.stack([imgs[i] for i in idx]), img_size)
+            imgs = out
         with torch.no_grad():
             dets = non_max_suppression(model(imgs), conf_thres, nms_thres)
         now = time.time()

@@ -184,6 +184,12 @@ int ay_build_targets(const float* pred_boxes, const float* pred_cls, const float
 int ay_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, ay_stream_t stream);
 
+/* ---- tile ingest ----------------------------------------------------------------- */
+/* uint8 HWC RGB tiles [B,H,W,3] -> float32 NCHW [B,3,S,S]: x/255 (utils/transforms.py:96), centre zero pad to square
+ * (utils/datasets.py:22-32), nearest resize src = min(floor(dst * (float)in/out), in-1) (utils/datasets.py:35-37), one pass. */
+int ay_ingest_tiles_u8(const void* img_hwc_u8, int batch, int h, int w, int out_size, float pad_value, float* out_nchw,
+                       ay_stream_t stream);
+
 /* ---- training step, bf16 MFMA path (blocked bf16 activations and activation gradients) ------------- */
 
 /* Train-mode BatchNorm + LeakyReLU (+ fused shortcut add of `skip`) around the MFMA convolution: statistics pass (fp64

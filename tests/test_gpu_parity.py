@@ -350,3 +350,60 @@ def test_model_bf16_vs_bf16_oracle(tmp_cfg_dir, dev, case):
     rel = np.abs(out[..., :4] - ref[..., :4]) / box_scale
     assert np.quantile(rel, 0.999) <= 5e-2, float(np.quantile(rel, 0.999))
     m.keep_layer_outputs = False
+
+
+@pytest.mark.parametrize("hw_size", [((64, 64), 64), ((37, 53), 64), ((53, 37), 96), ((600, 800), 416), ((100, 80), 416),
+                                      ((1536, 1536), 1024), ((1, 7), 32)], ids=str)
+def test_ingest_tiles_u8(hw_size):
+    """ay_ingest_tiles_u8 == ToTensor + pad_to_square + nearest resize of the reference (ATen CPU ops), bit for bit."""
+    from amyloid_yolo_paper_amd import datasets as D
+    from oracle import ingest_oracle as io
+    (h, w), size = hw_size
+    rng = np.random.Generator(np.random.PCG64(h * 1000 + w))
+    tiles = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    got = D.ingest_tiles_device(tiles, size).cpu()
+    for b in range(2):
+        ref = io.ingest(tiles[b], size)
+        assert torch.equal(got[b], ref), (hw_size, float((got[b] - ref).abs().max()))
+    # host composition of this package (what ImageFolder does) agrees too
+    host = D.resize(D.pad_to_square(D.to_tensor(tiles[0]))[0], size)
+    assert torch.equal(got[0], host)
+
+
+def test_detect_end_to_end(tmp_cfg_dir, tmp_path, dev):
+    """detect(): image files of mixed sizes -> rescaled boxes, through the .weights boundary, with the GPU ingest and with
+    the host transforms (identical results), and against the oracle pipeline (fp32: boxes within 1e-4, same kept rows)."""
+    from PIL import Image
+    from amyloid_yolo_paper_amd.detect import detect
+    from oracle import ingest_oracle as io
+    C_, S = 2, 128
+    _, o = build_models(C_, tmp_cfg_dir, dev, "fp32")
+    cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
+    wpath = os.path.join(tmp_cfg_dir, f"synth_c{C_}.weights")
+    folder = tmp_path / "imgs"
+    folder.mkdir()
+    sizes = [(128, 128), (100, 160), (160, 100), (128, 128), (200, 200)]
+    tiles = []
+    for i, (h, w) in enumerate(sizes):
+        t = np.ascontiguousarray(synth.synth_tile(40 + i, 256)[:h, :w])  # uint8 HWC
+        Image.fromarray(t).save(str(folder / f"t{i}.png"))
+        tiles.append(t)
+    kw = dict(image_folder=str(folder), model_def=cfg, weights_path=wpath, conf_thres=0.5, nms_thres=0.4, batch_size=3, img_size=S,
+              precision="fp32", verbose=False)
+    paths, res_dev, _ = detect(device_ingest=True, **kw)
+    paths2, res_host, _ = detect(device_ingest=False, **kw)
+    assert paths == paths2 and len(paths) == len(sizes)
+    n_boxes = 0
+    for i, (a, b) in enumerate(zip(res_dev, res_host)):
+        assert (a is None) == (b is None)
+        x = io.ingest(tiles[i], S).unsqueeze(0)
+        with torch.no_grad():
+            ref = bo.non_max_suppression(o.forward(x).numpy().copy(), 0.5, 0.4)[0][0]
+        assert (a is None) == (ref is None), i
+        if a is None:
+            continue
+        assert torch.equal(a, b), i
+        ref = bo.rescale_boxes(np.array(ref, np.float32), S, sizes[i])
+        close(a.numpy(), ref, TOL, f"image {i}")
+        n_boxes += a.shape[0]
+    assert n_boxes > 0
