@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     int cur = 0;  // ring slot of the stage the MFMAs read
     int par = 0;  // scale/shift region of the item the MFMAs work on
     const bool clk = (a.dbg & 8) && tid == 0;
-    unsigned long long tk_stage = 0, tk_epi = 0, tk_items = 0, tk0 = 0, tk_begin = 0;
+    unsigned long long tk_stage = 0, tk_epi = 0, tk_items = 0, tk0 = 0, tk_begin = 0, tk_s0 = 0;
     if (clk) tk_begin = wall_clock64();
     while (true) {
         if (clk) tk0 = wall_clock64();
@@ -823,6 +823,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 asm volatile("" ::: "memory");
             }
             if (++cur == NBUF) cur = 0;
+            if (clk && s == 0) tk_s0 += wall_clock64() - tk0;
         }
         if (clk) {
             const unsigned long long t = wall_clock64();
@@ -845,6 +846,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         atomicAdd(&g_phase_ticks[2], tk_items);
         atomicAdd(&g_phase_ticks[3], 1ull);
         atomicAdd(&g_phase_ticks[4], wall_clock64() - tk_begin);
+        atomicAdd(&g_phase_ticks[5], tk_s0);
     }
 }
 
@@ -945,9 +947,9 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
         if (t[3])
-            fprintf(stderr, "[ay phase] k%d s%d BN%d tile%dx%d cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us, epilogue %.2f us; wg total %.1f us\n",
+            fprintf(stderr, "[ay phase] k%d s%d BN%d tile%dx%d cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us (first stage %.2f of %d), epilogue %.2f us; wg total %.1f us\n",
                     KS, STRIDE, BN, TH, TW, d->cin, d->cout, d->hout, residual ? 1 : 0, (double)t[2] / t[3], t[0] * 0.01 / t[2],
-                    t[1] * 0.01 / t[2], t[4] * 0.01 / t[3]);
+                    t[5] * 0.01 / t[2], d->cin / (16 * NK), t[1] * 0.01 / t[2], t[4] * 0.01 / t[3]);
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
     }

@@ -169,6 +169,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                         unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
                         auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                         auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
+                        // plain stores: `nt` (streaming) stores were measured slower -- their completion, which the next stage's
+                        // counted DMA wait sits behind, takes longer (first stage of the next item 4.0 -> 5.1 us)
                         if (ok && !(a.dbg & 4)) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                     }
                 }
