@@ -33,7 +33,8 @@ static inline int next_pow2(int v) {
 }
 
 // workspace layout per image (cap = next_pow2(n_rows)):
-//   keys  u64[cap] | cand f32[8][cap] (x1,y1,x2,y2,conf,cls_conf,cls_pred,row-as-int)
+//   keys  u64[cap] | cand f32[8][cap] (x1,y1,x2,y2,conf,cls_conf,cls_pred,row-as-int) | alive u64[cap/64] (only used
+//   when an image has more than 65 536 candidates; smaller alive sets live in LDS)
 struct NmsWs {
     unsigned long long* keys;
     float* cand;
@@ -91,10 +92,9 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
                                                         unsigned long long* keys, float* cand, int cap,
                                                         const int* __restrict__ cand_count, int max_det,
                                                         float* __restrict__ out_rows, int* __restrict__ keep_idx,
-                                                        int* __restrict__ count) {
+                                                        int* __restrict__ count, unsigned long long* alive_ws) {
     __shared__ unsigned long long skeys[NMS_LDS_KEYS];
-    __shared__ unsigned long long alive_s[1024];  // up to 65536 candidates
-    volatile unsigned long long* alive = alive_s;  // lane 0 publishes, all lanes re-read: never cache
+    __shared__ unsigned long long alive_s[1024];  // up to 65536 candidates; larger sets (2048^2 tiles at a low threshold) use the workspace
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int K = 5 + C;
@@ -144,11 +144,13 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
         reinterpret_cast<int*>(cb)[7 * cap + i] = r;
     }
     const int nwords = (n + 63) >> 6;
+    // lane 0 publishes, all lanes re-read: never cache (volatile: LDS, or L2-coherent global accesses of one wave)
+    volatile unsigned long long* alive = nwords <= 1024 ? alive_s : alive_ws + (size_t)b * (cap >> 6);
     for (int i = tid; i < nwords; i += 256) {
         const int rem = n - i * 64;
         alive[i] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     }
-    __threadfence_block();
+    __threadfence();
     __syncthreads();
     if (tid >= 64) return;
     // ---- greedy scan by one wavefront ---------------------------------------------------------------
@@ -216,12 +218,12 @@ using namespace ay;
 extern "C" size_t ay_nms_workspace_bytes(int batch, int n_rows) {
     if (batch <= 0 || n_rows <= 0) return 0;
     const size_t cap = (size_t)next_pow2(n_rows);
-    return (size_t)batch * cap * (8 + 8 * 4);
+    return (size_t)batch * cap * (8 + 8 * 4) + (size_t)batch * (cap / 64 + 1) * 8;
 }
 
 static int nms_args_ok(int batch, int n_rows, int num_classes, size_t workspace_bytes, const char* who) {
-    if (!(batch > 0 && n_rows > 0 && n_rows <= 65536 && num_classes >= 1)) {
-        set_error("%s: bad shape (1 <= rows <= 65536)", who);
+    if (!(batch > 0 && n_rows > 0 && n_rows <= (1 << 24) && num_classes >= 1)) {
+        set_error("%s: bad shape (1 <= rows <= 2^24)", who);
         return AY_ERR_ARG;
     }
     if (workspace_bytes < ay_nms_workspace_bytes(batch, n_rows)) {
@@ -257,8 +259,9 @@ extern "C" int ay_nms_sort_merge(const float* pred, int batch, int n_rows, int n
     const int cap = next_pow2(n_rows);
     unsigned long long* keys = (unsigned long long*)workspace;
     float* cand = (float*)((char*)workspace + (size_t)batch * cap * 8);
+    unsigned long long* alive_ws = (unsigned long long*)((char*)workspace + (size_t)batch * cap * (8 + 8 * 4));
     hipLaunchKernelGGL(nms_merge_kernel, dim3(batch), dim3(256), 0, S(stream), pred, n_rows, num_classes, nms_thres, keys, cand, cap,
-                       cand_count, max_det, out_rows, keep_idx, count);
+                       cand_count, max_det, out_rows, keep_idx, count, alive_ws);
     AY_CHECK_LAUNCH("nms_merge_kernel");
     return AY_OK;
 }
