@@ -54,6 +54,7 @@ _SIGS = {
     "ay_ingest_tiles_u8": (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
     "ay_build_targets_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ay_build_targets": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ay_yolo_loss_giou_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
     "ay_adam_flat": (_I, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _F, _P]),
     "ay_bn_train_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_bn_train_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

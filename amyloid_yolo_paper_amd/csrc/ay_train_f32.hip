@@ -249,6 +249,41 @@ __device__ __forceinline__ float iou_cxcywh_p1(float ax, float ay, float aw, flo
     return inter / (a1 + a2 - inter + 1e-16f);
 }
 
+// GIoU box loss (new feature, no reference counterpart -- SURVEY F3): L = 1 - GIoU(pred, target) on corner boxes without the
+// +1 rule (same formula as ay_box_iou mode 1), and its gradient with respect to the predicted box (cx, cy, w, h).
+__device__ __forceinline__ float giou_loss_grad(float bx, float by, float bw, float bh, float gx, float gy, float gw, float gh,
+                                                float* dbox /* [4] or nullptr */) {
+    const float x1 = bx - bw / 2.0f, x2 = bx + bw / 2.0f, y1 = by - bh / 2.0f, y2 = by + bh / 2.0f;
+    const float X1 = gx - gw / 2.0f, X2 = gx + gw / 2.0f, Y1 = gy - gh / 2.0f, Y2 = gy + gh / 2.0f;
+    const float iwr = fminf(x2, X2) - fmaxf(x1, X1), ihr = fminf(y2, Y2) - fmaxf(y1, Y1);
+    const float iw = fmaxf(iwr, 0.0f), ih = fmaxf(ihr, 0.0f);
+    const float inter = iw * ih;
+    const float w1 = x2 - x1, h1 = y2 - y1;
+    const float U = w1 * h1 + (X2 - X1) * (Y2 - Y1) - inter + 1e-16f;
+    const float cw = fmaxf(x2, X2) - fminf(x1, X1), ch = fmaxf(y2, Y2) - fminf(y1, Y1);
+    const float Ch = cw * ch + 1e-16f;
+    const float loss = 1.0f - (inter / U - (Ch - U) / Ch);
+    if (dbox) {
+        // per corner c in (x1, x2, y1, y2): d inter, d area, d hull
+        const float di[4] = {(iwr > 0.0f && x1 > X1) ? -ih : 0.0f, (iwr > 0.0f && x2 < X2) ? ih : 0.0f,
+                             (ihr > 0.0f && y1 > Y1) ? -iw : 0.0f, (ihr > 0.0f && y2 < Y2) ? iw : 0.0f};
+        const float da[4] = {-h1, h1, -w1, w1};
+        const float dc[4] = {(x1 < X1) ? -ch : 0.0f, (x2 > X2) ? ch : 0.0f, (y1 < Y1) ? -cw : 0.0f, (y2 > Y2) ? cw : 0.0f};
+        float dl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float dU = da[c] - di[c];
+            const float dg = (di[c] * U - inter * dU) / (U * U) + (dU * Ch - U * dc[c]) / (Ch * Ch);
+            dl[c] = -dg;
+        }
+        dbox[0] = dl[0] + dl[1];
+        dbox[1] = dl[2] + dl[3];
+        dbox[2] = 0.5f * (dl[1] - dl[0]);
+        dbox[3] = 0.5f * (dl[3] - dl[2]);
+    }
+    return loss;
+}
+
 // cell state words: bit0 obj, bit1 "noobj cleared" (best anchor or ignore threshold); winner[cell] = last target index
 // (the reference's scatter is last-writer-wins in target order: utils/utils.py:310-327).
 __global__ void yolo_targets_pass1(const float* __restrict__ tgt, int nT, YoloGeom g, float ignore_thres, int* __restrict__ winner,
@@ -282,7 +317,7 @@ __global__ void yolo_targets_pass1(const float* __restrict__ tgt, int nT, YoloGe
 //       [10] conf_obj_sum [11] conf_noobj_sum [12] conf50_sum [13] iou50*det [14] iou75*det
 __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __restrict__ tgt, YoloGeom g, const int* __restrict__ winner,
                                const unsigned* __restrict__ flags, const float* __restrict__ tcls, float* __restrict__ sums,
-                               float* __restrict__ dhead, int phase, float grad_scale) {
+                               float* __restrict__ dhead, int phase, float grad_scale, int box_loss) {
     // phase 0: accumulate sums (losses un-normalised + counts); phase 1: write dL/dhead using the counts in sums
     const int cells = g.B * g.A * g.G * g.G;
     const int K = 5 + g.C;
@@ -318,10 +353,14 @@ __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __re
         const float px = head[base], py = head[base + cs], pw = head[base + 2 * cs], ph = head[base + 3 * cs];
         const float sx = sigm(px), sy = sigm(py);
         if (phase == 0) {
-            loc[0] += (sx - tx) * (sx - tx);
-            loc[1] += (sy - ty) * (sy - ty);
-            loc[2] += (pw - tw) * (pw - tw);
-            loc[3] += (ph - th) * (ph - th);
+            if (box_loss == 1) {  // GIoU variant: one term replaces the four squared errors
+                loc[0] += giou_loss_grad(sx + gi, sy + gj, expf(pw) * g.aw[a], expf(ph) * g.ah[a], gx, gy, gw, gh, nullptr);
+            } else {
+                loc[0] += (sx - tx) * (sx - tx);
+                loc[1] += (sy - ty) * (sy - ty);
+                loc[2] += (pw - tw) * (pw - tw);
+                loc[3] += (ph - th) * (ph - th);
+            }
             loc[4] += -fmaxf(logf(pc), -100.0f);
             loc[7] += 1.f;
             loc[10] += pc;
@@ -345,10 +384,20 @@ __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __re
         } else {
             const float n_obj = sums[7];
             const float s = grad_scale / n_obj;
-            dhead[base] = s * 2.0f * (sx - tx) * sx * (1.0f - sx);
-            dhead[base + cs] = s * 2.0f * (sy - ty) * sy * (1.0f - sy);
-            dhead[base + 2 * cs] = s * 2.0f * (pw - tw);
-            dhead[base + 3 * cs] = s * 2.0f * (ph - th);
+            if (box_loss == 1) {
+                const float bw = expf(pw) * g.aw[a], bh = expf(ph) * g.ah[a];
+                float db[4];
+                giou_loss_grad(sx + gi, sy + gj, bw, bh, gx, gy, gw, gh, db);
+                dhead[base] = s * db[0] * sx * (1.0f - sx);   // d(cx)/d(tx) = sigmoid'
+                dhead[base + cs] = s * db[1] * sy * (1.0f - sy);
+                dhead[base + 2 * cs] = s * db[2] * bw;        // d(w)/d(tw) = w
+                dhead[base + 3 * cs] = s * db[3] * bh;
+            } else {
+                dhead[base] = s * 2.0f * (sx - tx) * sx * (1.0f - sx);
+                dhead[base + cs] = s * 2.0f * (sy - ty) * sy * (1.0f - sy);
+                dhead[base + 2 * cs] = s * 2.0f * (pw - tw);
+                dhead[base + 3 * cs] = s * 2.0f * (ph - th);
+            }
             dhead[base + 4 * cs] += s * bce_logit_grad(pc, 1.0f);  // obj cells are never noobj: the += lands on 0
             for (int k = 0; k < g.C; ++k) {
                 const float p = sigm(head[base + (5 + k) * cs]);
@@ -518,10 +567,10 @@ extern "C" size_t ay_yolo_loss_workspace_bytes(int batch, int num_anchors, int n
     return cells * 4 /*winner*/ + cells * 4 /*flags*/ + cells * num_classes * 4 /*tcls*/ + 64 * 4 /*sums*/;
 }
 
-extern "C" int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors,
-                                    int num_classes, int grid, int img_dim, const float* anchors_wh, float ignore_thres, float grad_scale,
-                                    float* dhead, float* sums_out /* device, 16 floats */, void* workspace, size_t workspace_bytes,
-                                    ay_stream_t stream) {
+static int yolo_loss_impl(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors, int num_classes,
+                          int grid, int img_dim, const float* anchors_wh, float ignore_thres, float grad_scale, float* dhead,
+                          float* sums_out /* device, 16 floats */, void* workspace, size_t workspace_bytes, ay_stream_t stream,
+                          int box_loss) {
     AY_CHECK_ARG(head_nchw && anchors_wh && dhead && sums_out && workspace, "ay_yolo_loss_fwd_bwd: null");
     AY_CHECK_ARG(num_anchors > 0 && num_anchors <= 8 && num_classes >= 1 && grid > 0, "ay_yolo_loss_fwd_bwd: bad shape");
     AY_CHECK_ARG(n_targets == 0 || targets, "ay_yolo_loss_fwd_bwd: targets null");
@@ -555,15 +604,30 @@ extern "C" int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets
         AY_CHECK_LAUNCH("yolo_targets_pass1");
     }
     const unsigned gr = gridn(cells);
-    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 0, grad_scale);
+    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 0, grad_scale, box_loss);
     AY_CHECK_LAUNCH("yolo_loss_pass(0)");
-    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 1, grad_scale);
+    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 1, grad_scale, box_loss);
     AY_CHECK_LAUNCH("yolo_loss_pass(1)");
     if (hipMemcpyAsync(sums_out, sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("ay_yolo_loss_fwd_bwd: copy failed");
         return AY_ERR_LAUNCH;
     }
     return AY_OK;
+}
+
+extern "C" int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors,
+                                    int num_classes, int grid, int img_dim, const float* anchors_wh, float ignore_thres, float grad_scale,
+                                    float* dhead, float* sums_out, void* workspace, size_t workspace_bytes, ay_stream_t stream) {
+    return yolo_loss_impl(head_nchw, targets, n_targets, batch, num_anchors, num_classes, grid, img_dim, anchors_wh, ignore_thres, grad_scale,
+                          dhead, sums_out, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int ay_yolo_loss_giou_fwd_bwd(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors,
+                                         int num_classes, int grid, int img_dim, const float* anchors_wh, float ignore_thres,
+                                         float grad_scale, float* dhead, float* sums_out, void* workspace, size_t workspace_bytes,
+                                         ay_stream_t stream) {
+    return yolo_loss_impl(head_nchw, targets, n_targets, batch, num_anchors, num_classes, grid, img_dim, anchors_wh, ignore_thres, grad_scale,
+                          dhead, sums_out, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" size_t ay_build_targets_workspace_bytes(int batch, int num_anchors, int grid) {

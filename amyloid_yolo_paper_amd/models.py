@@ -116,6 +116,8 @@ class Darknet(nn.Module):
         self.keep_layer_outputs = False
         self.layer_outputs = None
         self.stem_mode = "fused_bf16"   # "fp32": separate fp32 stem kernel (layer 0 output materialised)
+        self.box_loss = "mse"           # "giou": 1 - GIoU replaces the four squared-error box terms (new feature; the
+                                        # reference has only the MSE form, models.py:183-186)
 
     # ------------------------------------------------------------------ graph analysis
     def _analyse(self):

@@ -33,14 +33,18 @@ def format_metrics(model, epoch, epochs, batch_i, n_batches):
 
 def train(epochs=100, batch_size=8, gradient_accumulations=2, model_def="config/yolov3.cfg", data_config="config/coco.data",
           pretrained_weights=None, n_cpu=8, img_size=416, checkpoint_interval=1, evaluation_interval=1,
-          multiscale_training=True, verbose=False, checkpoint_dir="checkpoints", max_batches=None, seed=0):
+          multiscale_training=True, verbose=False, checkpoint_dir="checkpoints", max_batches=None, seed=0, precision="bf16",
+          box_loss="mse"):
+    """``precision``: "bf16" = MFMA training path (bf16 activations/gradients, fp32 master weights and statistics),
+    "fp32" = the parity path that reproduces the reference's fp32 step to 1e-4.  ``box_loss``: "mse" (reference) | "giou"."""
     rank, local_rank, world = init_distributed()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     torch.manual_seed(seed)
     cfg = parse_data_config(data_config)
     class_names = load_classes(cfg["names"])
-    model = Darknet(model_def, precision="fp32").to(dev)
+    model = Darknet(model_def, precision=precision).to(dev)
+    model.box_loss = box_loss
     model.apply(weights_init_normal)
     if pretrained_weights:
         if pretrained_weights.endswith(".pth"):
@@ -103,9 +107,12 @@ def main(argv=None):
     ap.add_argument("--multiscale_training", default=True)
     ap.add_argument("--verbose", "-v", default=False, action="store_true")
     ap.add_argument("--logdir", type=str, default="logs")
+    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--box_loss", type=str, default="mse", choices=["mse", "giou"])
     o = ap.parse_args(argv)
     train(o.epochs, o.batch_size, o.gradient_accumulations, o.model_def, o.data_config, o.pretrained_weights, o.n_cpu, o.img_size,
-          o.checkpoint_interval, o.evaluation_interval, o.multiscale_training not in (False, "False"), o.verbose)
+          o.checkpoint_interval, o.evaluation_interval, o.multiscale_training not in (False, "False"), o.verbose,
+          precision=o.precision, box_loss=o.box_loss)
 
 
 if __name__ == "__main__":

@@ -157,7 +157,7 @@ def train_forward(model, x, targets):
                 sums = torch.empty(16, device=dev, dtype=torch.float32)
                 nb = L.ay_yolo_loss_workspace_bytes(B, y.num_anchors, y.num_classes, G)
                 ws = _ws(model, nb, dev)
-                check(L.ay_yolo_loss_fwd_bwd(ptr(head), ptr(tg), tg.shape[0], B, y.num_anchors, y.num_classes, G, S, anchors,
+                check((L.ay_yolo_loss_giou_fwd_bwd if getattr(model, 'box_loss', 'mse') == 'giou' else L.ay_yolo_loss_fwd_bwd)(ptr(head), ptr(tg), tg.shape[0], B, y.num_anchors, y.num_classes, G, S, anchors,
                                              C.c_float(y.ignore_thres), C.c_float(1.0), ptr(dhead), ptr(sums), ptr(ws), ws.numel(), st),
                       "ay_yolo_loss_fwd_bwd")
                 stt.dhead[i] = dhead

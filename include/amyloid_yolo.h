@@ -170,6 +170,13 @@ int ay_yolo_loss_fwd_bwd(const float* head_nchw, const float* targets, int n_tar
                          int num_classes, int grid, int img_dim, const float* anchors_wh /* host */, float ignore_thres,
                          float grad_scale, float* dhead, float* sums_out, void* workspace, size_t workspace_bytes,
                          ay_stream_t stream);
+/* GIoU variant of the box term (BASELINE.json configs[4]; new feature, no reference counterpart): same call, same sums
+ * layout, but sums[0] = sum over object cells of 1 - GIoU(decoded box, target box) (grid units, no +1 rule) and
+ * sums[1..3] = 0; loss = s0/n_obj + s4/n_obj + 100*s5/n_noobj + s6/(n_obj*C). */
+int ay_yolo_loss_giou_fwd_bwd(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors,
+                              int num_classes, int grid, int img_dim, const float* anchors_wh /* host */, float ignore_thres,
+                              float grad_scale, float* dhead, float* sums_out, void* workspace, size_t workspace_bytes,
+                              ay_stream_t stream);
 /* utils/utils.py:276-330 build_targets on device, as the dense 10-tuple the reference returns (same order):
  * pred_boxes [B,A,G,G,4] cxcywh in grid units, pred_cls [B,A,G,G,C], targets [nT,6] (sample, class, cx, cy, w, h in [0,1]),
  * anchors_grid (HOST) [A,2] = anchors / stride (models.py:123).  Masks are bytes (0/1).  Duplicate (sample, anchor, cell)

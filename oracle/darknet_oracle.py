@@ -35,6 +35,18 @@ def parse_cfg(path):
     return blocks
 
 
+def giou_cxcywh(b1, b2):
+    """GIoU of (cx,cy,w,h) boxes [n,4] x [n,4] with torch ops (differentiable); same formula as boxes_oracle.bbox_giou."""
+    x1, x2, y1, y2 = b1[:, 0] - b1[:, 2] / 2, b1[:, 0] + b1[:, 2] / 2, b1[:, 1] - b1[:, 3] / 2, b1[:, 1] + b1[:, 3] / 2
+    X1, X2, Y1, Y2 = b2[:, 0] - b2[:, 2] / 2, b2[:, 0] + b2[:, 2] / 2, b2[:, 1] - b2[:, 3] / 2, b2[:, 1] + b2[:, 3] / 2
+    iw = (torch.min(x2, X2) - torch.max(x1, X1)).clamp(min=0)
+    ih = (torch.min(y2, Y2) - torch.max(y1, Y1)).clamp(min=0)
+    inter = iw * ih
+    union = (x2 - x1) * (y2 - y1) + (X2 - X1) * (Y2 - Y1) - inter + 1e-16
+    hull = (torch.max(x2, X2) - torch.min(x1, X1)) * (torch.max(y2, Y2) - torch.min(y1, Y1)) + 1e-16
+    return inter / union - (hull - union) / hull
+
+
 def _bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
@@ -66,6 +78,7 @@ class OracleDarknet:
             filters.append(f)
         self.seen = 0
         self.metrics = []
+        self.box_loss = "mse"  # "giou": 1 - GIoU box term (no reference counterpart: parity unpinned, checked against autograd)
 
     # ---- weights (models.py:257-308) -------------------------------------------------
     def load_darknet_weights(self, path):
@@ -180,8 +193,19 @@ class OracleDarknet:
         tg = bo.build_targets(boxes.numpy(), cls.detach().numpy(), targets.numpy(), sa.numpy(), 0.5)
         iou_scores, class_mask, obj, noobj, tx, ty, tw, th, tcls, tconf = [torch.from_numpy(np.ascontiguousarray(v)) for v in tg]
         mse, bce = F.mse_loss, F.binary_cross_entropy
-        lx, ly = mse(sx[obj], tx[obj]), mse(sy[obj], ty[obj])
-        lw, lh = mse(w[obj], tw[obj]), mse(h[obj], th[obj])
+        if self.box_loss == "giou":
+            # published GIoU on corner boxes in grid units (no +1 rule), target box of the winning target per cell
+            gi = gx.expand(B, A, G, G)[obj]
+            gj = gy.expand(B, A, G, G)[obj]
+            aw = sa[:, 0].view(1, A, 1, 1).expand(B, A, G, G)[obj]
+            ah = sa[:, 1].view(1, A, 1, 1).expand(B, A, G, G)[obj]
+            pb = torch.stack((sx[obj] + gi, sy[obj] + gj, torch.exp(w[obj]) * aw, torch.exp(h[obj]) * ah), 1)
+            tb = torch.stack((tx[obj] + gi, ty[obj] + gj, torch.exp(tw[obj]) * aw, torch.exp(th[obj]) * ah), 1)
+            lx = (1.0 - giou_cxcywh(pb, tb)).mean()
+            ly = lw = lh = torch.zeros(())
+        else:
+            lx, ly = mse(sx[obj], tx[obj]), mse(sy[obj], ty[obj])
+            lw, lh = mse(w[obj], tw[obj]), mse(h[obj], th[obj])
         lconf_obj = bce(conf[obj], tconf[obj])
         lconf_noobj = bce(conf[noobj], tconf[noobj])
         lconf = 1 * lconf_obj + 100 * lconf_noobj

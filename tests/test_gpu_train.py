@@ -224,7 +224,8 @@ def test_adam_flat_matches_torch():
     assert (p.cpu() - p_ref.detach()).abs().max() <= 1e-6
 
 
-def test_train_loop_checkpoint_and_eval(tmp_path, tmp_cfg_dir):
+@pytest.mark.parametrize("precision,box_loss", [("fp32", "mse"), ("bf16", "giou")])
+def test_train_loop_checkpoint_and_eval(tmp_path, tmp_cfg_dir, precision, box_loss):
     """train() end to end on a tiny on-disk dataset: label txt format, collate, 3 optimiser steps with the reference's
     accumulation rule, per-layer metrics, state_dict checkpoint that the inference path loads back."""
     from PIL import Image
@@ -249,7 +250,8 @@ def test_train_loop_checkpoint_and_eval(tmp_path, tmp_cfg_dir):
     (tmp_path / "custom.data").write_text(f"classes= 2\ntrain={tmp_path}/train.txt\nvalid={tmp_path}/valid.txt\nnames={tmp_path}/classes.names\n")
     cfg = cfg_gen.write_cfg(2, tmp_cfg_dir)
     model, hist = train(epochs=1, batch_size=2, gradient_accumulations=2, model_def=cfg, data_config=str(tmp_path / "custom.data"),
-                        n_cpu=0, img_size=96, multiscale_training=False, checkpoint_dir=str(tmp_path / "ckpt"), max_batches=4)
+                        n_cpu=0, img_size=96, multiscale_training=False, checkpoint_dir=str(tmp_path / "ckpt"), max_batches=4,
+                        precision=precision, box_loss=box_loss)
     assert len(hist) == 4 and all(np.isfinite(hist))
     assert set(model.yolo_layers[0].metrics) == {"loss", "x", "y", "w", "h", "conf", "cls", "cls_acc", "recall50", "recall75",
                                                  "precision", "conf_obj", "conf_noobj", "grid_size"}
@@ -309,3 +311,78 @@ def test_build_targets_device_duplicates_and_empty():
     assert out[8].cpu().numpy().sum(-1).max() == 2.0  # a multi-hot cell exists in this case
     out = U.build_targets(torch.from_numpy(pb), torch.from_numpy(pc), torch.zeros(0, 6), torch.from_numpy(anc), 0.5)
     assert not out[2].any() and out[3].all() and all(float(out[i].abs().sum()) == 0.0 for i in (0, 1, 4, 5, 6, 7, 8, 9))
+
+
+def test_yolo_giou_loss_kernel_vs_autograd():
+    """GIoU box-loss variant (BASELINE configs[4]; no reference counterpart): loss and d loss / d head against torch
+    autograd of the published GIoU formula composed with the reference's conf/cls terms (tolerance 1e-4 relative)."""
+    import torch.nn.functional as F
+    from oracle.darknet_oracle import giou_cxcywh
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    B, A, Cc, G, S = 3, 3, 3, 16, 128
+    rng = np.random.Generator(np.random.PCG64(15))
+    head = torch.from_numpy(rng.normal(0, 0.8, (B, A * (5 + Cc), G, G)).astype(np.float32))
+    tg = synth.synth_targets(B, Cc, seed=31, max_per_tile=9, min_per_tile=4, wh_range=(0.05, 0.5), grid=G)
+    anchors = [(10, 13), (16, 30), (33, 23)]
+    h = head.clone().requires_grad_(True)
+    p = h.view(B, A, 5 + Cc, G, G).permute(0, 1, 3, 4, 2)
+    sx, sy, w, hh = torch.sigmoid(p[..., 0]), torch.sigmoid(p[..., 1]), p[..., 2], p[..., 3]
+    conf, cls = torch.sigmoid(p[..., 4]), torch.sigmoid(p[..., 5:])
+    _, boxes, aux = bo.decode(head.numpy(), anchors, Cc, S)
+    sa = torch.from_numpy(np.asarray(aux["scaled_anchors"], np.float32))
+    bt = bo.build_targets(boxes, aux["cls"], tg, aux["scaled_anchors"], 0.5)
+    iou_scores, class_mask, obj, noobj, tx, ty, tw, th, tcls, tconf = [torch.from_numpy(np.ascontiguousarray(v)) for v in bt]
+    gi = torch.arange(G, dtype=torch.float32).view(1, 1, 1, G).expand(B, A, G, G)[obj]
+    gj = torch.arange(G, dtype=torch.float32).view(1, 1, G, 1).expand(B, A, G, G)[obj]
+    aw = sa[:, 0].view(1, A, 1, 1).expand(B, A, G, G)[obj]
+    ah = sa[:, 1].view(1, A, 1, 1).expand(B, A, G, G)[obj]
+    pb = torch.stack((sx[obj] + gi, sy[obj] + gj, torch.exp(w[obj]) * aw, torch.exp(hh[obj]) * ah), 1)
+    tb = torch.stack((tx[obj] + gi, ty[obj] + gj, torch.exp(tw[obj]) * aw, torch.exp(th[obj]) * ah), 1)
+    loss = ((1.0 - giou_cxcywh(pb, tb)).mean() + F.binary_cross_entropy(conf[obj], tconf[obj])
+            + 100 * F.binary_cross_entropy(conf[noobj], tconf[noobj]) + F.binary_cross_entropy(cls[obj], tcls[obj]))
+    loss.backward()
+    hd, td = head.to(dev), torch.from_numpy(tg).to(dev)
+    dhead = torch.empty_like(hd)
+    sums = torch.empty(16, device=dev)
+    ws = torch.empty(L.ay_yolo_loss_workspace_bytes(B, A, Cc, G), device=dev, dtype=torch.uint8)
+    an = (C.c_float * 6)(*[float(v) for a in anchors for v in a])
+    check(L.ay_yolo_loss_giou_fwd_bwd(ptr(hd), ptr(td), tg.shape[0], B, A, Cc, G, S, an, C.c_float(0.5), C.c_float(1.0), ptr(dhead),
+                                      ptr(sums), ptr(ws), ws.numel(), _lib.stream_ptr()))
+    s = sums.cpu().numpy().astype(np.float64)
+    assert s[1] == 0 and s[2] == 0 and s[3] == 0
+    got = s[0] / s[7] + s[4] / s[7] + 100 * s[5] / s[8] + s[6] / (s[7] * Cc)
+    assert abs(got - loss.item()) <= 1e-4 * abs(loss.item()), (got, loss.item())
+    g = h.grad.numpy()
+    d = dhead.cpu().numpy()
+    assert np.abs(d - g).max() <= 1e-4 * np.abs(g).max() + 1e-8, float(np.abs(d - g).max() / np.abs(g).max())
+    # the box-coordinate channels really carry gradient (not just conf/cls)
+    gv = g.reshape(B, A, 5 + Cc, G, G)[:, :, :4]
+    assert np.abs(gv).max() > 1e-4
+
+
+def test_train_step_giou_end_to_end(tmp_cfg_dir):
+    """model.box_loss = 'giou' through model(x, targets) + backward (fp32 path) against the oracle network with the same
+    option and torch autograd: loss 1e-4, head-filter gradients 2e-4 of their scale."""
+    from oracle.darknet_oracle import OracleDarknet
+    C_, S, B = 3, 96, 2
+    m = _model(C_, tmp_cfg_dir)
+    m.train()
+    m.box_loss = "giou"
+    cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
+    o = OracleDarknet(cfg)
+    o.set_params(synth.synth_params(parse_config.parse_model_config(cfg), seed=7))
+    o.box_loss = "giou"
+    o.require_grad()
+    tg = torch.from_numpy(gc.train_targets(B, C_, S, 23))
+    x = torch.from_numpy(gc.model_inputs(S, B, 12))
+    loss, _ = m(x, tg)
+    loss.backward()
+    lo, _ = o.forward(x, tg, train_bn=True)
+    lo.backward()
+    close(loss.item(), lo.item(), 1e-4, "giou loss")
+    for li in (81, 93, 105):
+        g = m.module_list[li][0].weight.grad.cpu().numpy()
+        ref = o.params[li]["weight"].grad.numpy()
+        assert np.abs(g - ref).max() <= 2e-4 * np.abs(ref).max(), (li, float(np.abs(g - ref).max() / np.abs(ref).max()))
+    assert m.yolo_layers[0].metrics["y"] == 0.0 and m.yolo_layers[0].metrics["x"] > 0.0
