@@ -14,7 +14,7 @@ def load(d, cname):
         if r["Counter_Name"] == cname:
             out[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
     items = list(out.values())
-    idx = [i for i, v in enumerate(items) if "stem_conv" in v[0]]
+    idx = [i for i, v in enumerate(items) if "stem" in v[0]]
     return items[idx[-1]:]
 
 
@@ -29,8 +29,12 @@ for (n, fv), (n2, wv) in zip(fs, ws):
     assert n == n2
     if "conv_bf16" in n or "stem" in n:
         i, e = convs[ci]; ci += 1
+        fused_stem = "stem_s2_fused" in n   # layers 0 and 1 in one kernel: fp32 image in, layer-1 output out
+        if fused_stem:
+            i, e = convs[ci]; ci += 1
+            e = dict(e, cin=3, stride=2)
         S = 1024 >> e["log2_down"]; Sin = S * e["stride"]
-        inb = 64 * Sin * Sin * e["cin"] * (4 if i == 0 else 2) / 1e6
+        inb = 64 * Sin * Sin * e["cin"] * (4 if (i == 0 or fused_stem) else 2) / 1e6
         outb = 64 * S * S * max(e["cout"], 32) * (4 if not e["bn"] else 2) / 1e6
         resb = outb if e["fuse_into_shortcut"] else 0
         fmb, wmb = fv * 1024 * 2 / 1e6, wv * 1024 / 1e6
