@@ -792,8 +792,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {
                 if (a.dbg & 2) break;
-                if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
+                if (t + 1 < NSTEP && !(a.dbg & 64)) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                // (unequal priorities for the two waves of a SIMD were measured slower: 21.4 vs 20.0 us compute-only)
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
