@@ -103,7 +103,7 @@ def main():
 
     # dominant kernel family: 3x3 stride-1 convs whose padded cout is a multiple of 128
     fam = [i for i, e in enumerate(model._graph) if e["type"] == "convolutional" and e["k"] == 3 and e["stride"] == 1
-           and e["cout"] % 128 == 0 and e["cin"] % 16 == 0]
+           and e["cout"] % 128 == 0 and e["cin"] % 16 == 0 and not (model.fuse_blocks and e.get("in_fused_block"))]
     fam_flops = sum(conv_flops(model._graph[i], a.batch, a.size) for i in fam)
     total_flops = sum(conv_flops(e, a.batch, a.size) for e in model._graph if e["type"] == "convolutional")
 

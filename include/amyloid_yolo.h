@@ -80,6 +80,18 @@ int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const flo
 int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
                      const float* shift, const void* residual, void* out, ay_stream_t stream);
 
+/* Fused Darknet-53 residual block (models.py:26-45 twice + the shortcut at :246-248):
+ * out = leaky(bn2(conv3x3(leaky(bn1(conv1x1(x)))))) + x, channels C -> C/2 -> C, in one kernel: the C/2-channel
+ * intermediate stays in LDS.  x/out blocked bf16 [B][C/16][H][W][16] (out != x); w1_packed = ay_pack_conv_weights_bf16 of
+ * the [C/2][C][1][1] filters (cout_pad C/2), w2_packed of the [C][C/2][3][3] filters (cout_pad C); scale/shift from
+ * ay_fold_bn.  Same rounding points as the two ay_conv_fwd_bf16 calls it replaces (one bf16 rounding of the intermediate,
+ * one of the output).  ay_resblock_supported(C) says whether C has a fused kernel (64 and 128); other blocks use the
+ * two-call path. */
+int ay_resblock_supported(int channels);
+int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
+                         const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
+                         int channels, int h, int w, ay_stream_t stream);
+
 /* route (models.py:244-245) + nearest x2 upsample (models.py:86-96) as one gather into a blocked bf16
  * tensor [B][(c1+c2)/16][H][W][16]: src1 [B][c1/16][H>>up1][W>>up1][16], src2 [B][c2/16][H][W][16]|NULL. */
 int ay_concat_upsample_bf16(const void* src1, int c1, int up1, const void* src2, int c2, void* out,

@@ -17,7 +17,7 @@ ci, tot, groups = 0, 0.0, {}
 for r in seq:
     n = r["Kernel_Name"]
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if "conv_bf16" in n or "stem" in n:
+    if "conv_bf16" in n or "stem" in n or "resblock" in n:
         i, e = convs[ci]; ci += 1
         S = 1024 >> e["log2_down"]
         fl = 2 * 64 * S * S * e["cout"] * e["cin"] * e["k"] ** 2
@@ -26,7 +26,13 @@ for r in seq:
             S1 = 1024 >> e1["log2_down"]
             fl += 2 * 64 * S1 * S1 * e1["cout"] * e1["cin"] * e1["k"] ** 2
             e = dict(e1, cin=3)
-        key = f"{e['cin']:4d}->{e['cout']:4d} k{e['k']} s{e['stride']} @{S:4d} {'res' if e['fuse_into_shortcut'] else '   '}"
+        blk = ""
+        if "resblock" in n:  # 1x1 + 3x3 + shortcut in one kernel
+            i, e1 = convs[ci]; ci += 1
+            fl += 2 * 64 * S * S * e1["cout"] * e1["cin"] * e1["k"] ** 2
+            e = dict(e1, cin=e["cin"])
+            blk = " fused block"
+        key = f"{e['cin']:4d}->{e['cout']:4d} k{e['k']} s{e['stride']} @{S:4d} {'res' if e['fuse_into_shortcut'] else '   '}{blk}"
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
         tot += dur
     else:

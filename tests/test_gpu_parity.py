@@ -407,3 +407,49 @@ def test_detect_end_to_end(tmp_cfg_dir, tmp_path, dev):
         close(a.numpy(), ref, TOL, f"image {i}")
         n_boxes += a.shape[0]
     assert n_boxes > 0
+
+
+@pytest.mark.parametrize("case", [(64, 40, 2), (128, 32, 2), (128, 13, 1), (64, 72, 1)], ids=str)
+def test_resblock_fused_kernel(dev, case):
+    """ay_resblock_fwd_bf16 (1x1 -> 3x3 -> +x in one kernel) is BIT-identical to the two ay_conv_fwd_bf16 calls it
+    replaces (same K order, same rounding points), and within 1 bf16 ulp (+1e-3) of the torch-CPU composition."""
+    Cc, H, B = case
+    CM = Cc // 2
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(Cc * 3 + H)
+    x = _bf16r(torch.randn(B, Cc, H, H, generator=g))
+    w1 = torch.randn(CM, Cc, 1, 1, generator=g) * (1.0 / np.sqrt(Cc))
+    w2 = torch.randn(Cc, CM, 3, 3, generator=g) * (1.0 / np.sqrt(CM * 9))
+    s1, t1 = torch.rand(CM, generator=g) + 0.5, torch.randn(CM, generator=g) * 0.1
+    s2, t2 = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    mid = _bf16r(F.leaky_relu(F.conv2d(x, _bf16r(w1)) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1), 0.1))
+    ref = _bf16r(F.leaky_relu(F.conv2d(mid, _bf16r(w2), None, 1, 1) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1), 0.1) + x)
+    xd, w1d, w2d = x.to(dev), w1.to(dev), w2.to(dev)
+    xb = torch.empty(B, Cc // 16, H, H, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(xd), ptr(xb), B, Cc, H, H, st))
+    p1 = torch.empty(L.ay_packed_weight_bytes(CM, Cc, 1), device=dev, dtype=torch.uint8)
+    p2 = torch.empty(L.ay_packed_weight_bytes(Cc, CM, 3), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_conv_weights_bf16(ptr(w1d), ptr(p1), CM, CM, Cc, 1, st))
+    check(L.ay_pack_conv_weights_bf16(ptr(w2d), ptr(p2), Cc, Cc, CM, 3, st))
+    s1d, t1d, s2d, t2d = s1.to(dev), t1.to(dev), s2.to(dev), t2.to(dev)
+    # two-call path
+    mb = torch.empty(B, CM // 16, H, H, 16, device=dev, dtype=torch.bfloat16)
+    o2 = torch.full((B, Cc // 16, H, H, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    d1 = ConvDesc(B, Cc, CM, H, H, H, H, 1, 1, 1, 0, CM)
+    d2 = ConvDesc(B, CM, Cc, H, H, H, H, 3, 1, 1, 0, Cc)
+    check(L.ay_conv_fwd_bf16(C.byref(d1), ptr(xb), ptr(p1), ptr(s1d), ptr(t1d), None, ptr(mb), st), "conv1")
+    check(L.ay_conv_fwd_bf16(C.byref(d2), ptr(mb), ptr(p2), ptr(s2d), ptr(t2d), ptr(xb), ptr(o2), st), "conv2")
+    # fused
+    assert L.ay_resblock_supported(Cc) == 1 and L.ay_resblock_supported(256) == 0
+    of = torch.full((B, Cc // 16, H, H, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(L.ay_resblock_fwd_bf16(ptr(xb), ptr(p1), ptr(s1d), ptr(t1d), 1, ptr(p2), ptr(s2d), ptr(t2d), 1, ptr(of), B, Cc, H, H, st),
+          "resblock")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(of.float()).all())
+    assert torch.equal(of.view(torch.int16), o2.view(torch.int16)), int((of.view(torch.int16) != o2.view(torch.int16)).sum())
+    got = torch.empty(B, Cc, H, H, device=dev)
+    check(L.ay_blocked_bf16_to_nchw_f32(ptr(of), ptr(got), B, Cc, H, H, st))
+    err = (got.cpu() - ref).abs()
+    bound = ref.abs() * 2.0 ** -6 + 2e-3   # two rounded layers: the intermediate may round the other way too
+    assert float((err > bound).float().mean()) <= 1e-3, (float((err > bound).float().mean()), float(err.max()))
