@@ -20,12 +20,15 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 }
 
 // ---- per-channel sums over (B,H,W) of a blocked bf16 tensor: sums[c] += sum z, sums[C + c] += sum z^2 (fp64 atomics)
-// grid (chunks, planes, batch); one thread = one 16-byte unit (pixel, 8 channels); lanes of equal parity share channels.
+// grid (pixel chunks, planes, batch groups); one thread = one 16-byte unit (pixel, 8 channels) per step, its channel
+// parameters in registers; thread parity = channel half (all strides are even).  The four waves of a workgroup are
+// reduced through LDS first: one atomic per channel per workgroup (contended fp64 atomics were most of this kernel).
 template <bool BWD>
 __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ a, const uint4* __restrict__ zt,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
                                                       double* __restrict__ sums, int C, int HW, int B) {
+    __shared__ float red[4][2][16];
     const int plane = blockIdx.y;
     const int CP = gridDim.y;
     const int half = threadIdx.x & 1;
@@ -43,29 +46,29 @@ __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ 
         }
     }
     const int units = HW * 2;
-    const long long all_units = (long long)B * units;
-    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < all_units; v += (long long)gridDim.x * 256) {  // even strides keep the parity
-        const int b = (int)(v / units);
-        const int u = (int)(v % units);
-        const size_t base = ((size_t)b * CP + plane) * HW * 2;
-        float f[8];
-        unpack8(a[base + u], f);
-        if (!BWD) {
+    const int stride = gridDim.x * 256;
+    for (int b = blockIdx.z; b < B; b += gridDim.z) {
+        const size_t base = ((size_t)b * CP + plane) * units;
+        for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += stride) {
+            float f[8];
+            unpack8(a[base + u], f);
+            if (!BWD) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s1[j] += f[j];
-                s2[j] += f[j] * f[j];
-            }
-        } else {  // a = dy, zt = z: s1 = sum dpre, s2 = sum dpre * xhat
-            float z[8];
-            unpack8(zt[base + u], z);
+                for (int j = 0; j < 8; ++j) {
+                    s1[j] += f[j];
+                    s2[j] += f[j] * f[j];
+                }
+            } else {  // a = dy, zt = z: s1 = sum dpre, s2 = sum dpre * xhat
+                float z[8];
+                unpack8(zt[base + u], z);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (z[j] - mu[j]) * is[j];
-                const float pre = xh * ga[j] + be[j];
-                const float d = (leaky && !(pre > 0.f)) ? 0.1f * f[j] : f[j];
-                s1[j] += d;
-                s2[j] += d * xh;
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (z[j] - mu[j]) * is[j];
+                    const float pre = xh * ga[j] + be[j];
+                    const float d = (leaky && !(pre > 0.f)) ? 0.1f * f[j] : f[j];
+                    s1[j] += d;
+                    s2[j] += d * xh;
+                }
             }
         }
     }
@@ -77,13 +80,19 @@ __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ 
             s2[j] += __shfl_xor(s2[j], off);
         }
     }
-    if ((threadIdx.x & 63) < 2) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (c0 + j < C) {
-                atomicAdd(&sums[c0 + j], (double)s1[j]);
-                atomicAdd(&sums[C + c0 + j], (double)s2[j]);
-            }
+        for (int j = 0; j < 8; ++j) {
+            red[wv][0][lane * 8 + j] = s1[j];
+            red[wv][1][lane * 8 + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {  // 16 channels x {sum, sum of squares}
+        const int which = threadIdx.x >> 4, ch = threadIdx.x & 15;
+        const float v = (red[0][which][ch] + red[1][which][ch]) + (red[2][which][ch] + red[3][which][ch]);
+        if (plane * 16 + ch < C) atomicAdd(&sums[which * C + plane * 16 + ch], (double)v);
     }
 }
 
@@ -110,26 +119,38 @@ __global__ void bn_finalize_bwd_kernel(const double* sums, float* dgamma, float*
 }
 
 // y = bf16( leaky(gamma * (z - mean) * invstd + beta) [+ skip] )
+// grid (pixel chunks, planes, batch): a thread keeps the parameters of its 8 channels in registers (they used to be 32
+// scalar loads per 16-byte unit) and walks pixels with an even stride.
 __global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int leaky, const uint4* __restrict__ skip,
-                                                       uint4* __restrict__ y, int C, int CP, int HW, size_t units) {
-    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
-        const int half = (int)(u & 1);
-        const int plane = (int)((u / 2 / HW) % CP);
-        const int c0 = plane * 16 + half * 8;
+                                                       uint4* __restrict__ y, int C, int CP, int HW) {
+    const int plane = blockIdx.y;
+    const int half = threadIdx.x & 1;
+    const int c0 = plane * 16 + half * 8;
+    float mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j < C ? c0 + j : C - 1;
+        mu[j] = mean[c];
+        is[j] = invstd[c];
+        ga[j] = gamma[c];
+        be[j] = beta[c];
+    }
+    const int units = HW * 2;
+    const size_t base = ((size_t)blockIdx.z * CP + plane) * units;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
         float f[8], s[8];
-        unpack8(z[u], f);
-        if (skip) unpack8(skip[u], s);
+        unpack8(z[base + u], f);
+        if (skip) unpack8(skip[base + u], s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j < C ? c0 + j : C - 1;
-            float v = (f[j] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+            float v = (f[j] - mu[j]) * is[j] * ga[j] + be[j];
             if (leaky) v = v > 0.f ? v : 0.1f * v;
             if (skip) v += s[j];
             f[j] = c0 + j < C ? v : 0.f;
         }
-        y[u] = pack8(f);
+        y[base + u] = pack8(f);
     }
 }
 
@@ -138,25 +159,37 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
                                                            const double* __restrict__ sums, float n, uint4* __restrict__ dz, int C, int CP,
-                                                           int HW, size_t units) {
-    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
-        const int half = (int)(u & 1);
-        const int plane = (int)((u / 2 / HW) % CP);
-        const int c0 = plane * 16 + half * 8;
+                                                           int HW) {
+    const int plane = blockIdx.y;
+    const int half = threadIdx.x & 1;
+    const int c0 = plane * 16 + half * 8;
+    float mu[8], is[8], ga[8], be[8], sb[8], sg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j < C ? c0 + j : C - 1;
+        mu[j] = mean[c];
+        is[j] = invstd[c];
+        ga[j] = gamma[c];
+        be[j] = beta[c];
+        sb[j] = (float)sums[c];
+        sg[j] = (float)sums[C + c];
+    }
+    const int units = HW * 2;
+    const size_t base = ((size_t)blockIdx.z * CP + plane) * units;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
         float d[8], zz[8];
-        unpack8(dy[u], d);
-        unpack8(z[u], zz);
+        unpack8(dy[base + u], d);
+        unpack8(z[base + u], zz);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j < C ? c0 + j : C - 1;
-            const float xh = (zz[j] - mean[c]) * invstd[c];
-            const float pre = xh * gamma[c] + beta[c];
+            const float xh = (zz[j] - mu[j]) * is[j];
+            const float pre = xh * ga[j] + be[j];
             const float dp = (leaky && !(pre > 0.f)) ? 0.1f * d[j] : d[j];
-            const float k = gamma[c] * invstd[c] / n;
-            const float v = k * (n * dp - (float)sums[c] - xh * (float)sums[C + c]);
+            const float k = ga[j] * is[j] / n;
+            const float v = k * (n * dp - sb[j] - xh * sg[j]);
             d[j] = c0 + j < C ? v : 0.f;
         }
-        dz[u] = pack8(d);
+        dz[base + u] = pack8(d);
     }
 }
 
@@ -243,6 +276,22 @@ __global__ void pack_dgrad_weights_kernel(const float* __restrict__ w, uint16_t*
     }
 }
 
+// grids of the BatchNorm passes: x = chunks of a plane's 2*HW units (>= 4 units per thread where the plane allows),
+// z = batch (apply passes) or up to 4 batch groups (sums: gx * bz workgroups issue one atomic per channel each)
+struct BnGrid {
+    int gx_sums, gx_apply, bz;
+};
+static inline BnGrid bn_grid(int batch, int HW) {
+    const int units = HW * 2;
+    int gx = (units + 4 * 256 - 1) / (4 * 256);
+    if (gx < 1) gx = 1;
+    BnGrid g;
+    g.gx_apply = gx > 64 ? 64 : gx;
+    g.gx_sums = gx > 32 ? 32 : gx;
+    g.bz = batch < 4 ? batch : 4;
+    return g;
+}
+
 static inline unsigned gridu(size_t units) {
     size_t g = (units + 255) / 256;
     if (g > 65535) g = 65535;
@@ -263,18 +312,15 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    long long gxl = ((long long)batch * HW * 2 + 4 * 256 - 1) / (4 * 256);  // >= 4 units per thread
-    const int cap = CP >= 64 ? 8 : (CP >= 16 ? 32 : 128);                      // ~512-2048 workgroups in all
-    const int gx = (int)(gxl < 1 ? 1 : (gxl > cap ? cap : gxl));
-    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(gx, CP), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+    const BnGrid g = bn_grid(batch, HW);
+    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(g.gx_sums, CP, g.bz), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
                        nullptr, 0, sums_ws, channels, HW, batch);
     AY_CHECK_LAUNCH("bn_sums_kernel");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, (double)batch * HW, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, channels);
     AY_CHECK_LAUNCH("bn_finalize_fwd_kernel");
-    const size_t units = (size_t)batch * CP * HW * 2;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(gridu(units)), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta, leaky,
-                       (const uint4*)skip, (uint4*)y, channels, CP, HW, units);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.gx_apply, CP, batch), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta,
+                       leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW);
     AY_CHECK_LAUNCH("bn_apply_kernel");
     return AY_OK;
 }
@@ -289,17 +335,14 @@ extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* 
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    long long gxl = ((long long)batch * HW * 2 + 4 * 256 - 1) / (4 * 256);
-    const int cap = CP >= 64 ? 8 : (CP >= 16 ? 32 : 128);
-    const int gx = (int)(gxl < 1 ? 1 : (gxl > cap ? cap : gxl));
-    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(gx, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
+    const BnGrid g = bn_grid(batch, HW);
+    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(g.gx_sums, CP, g.bz), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
                        gamma, beta, leaky, sums_ws, channels, HW, batch);
     AY_CHECK_LAUNCH("bn_sums_kernel<bwd>");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels);
     AY_CHECK_LAUNCH("bn_finalize_bwd_kernel");
-    const size_t units = (size_t)batch * CP * HW * 2;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gridu(units)), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
-                       gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW, units);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.gx_apply, CP, batch), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean,
+                       save_invstd, gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW);
     AY_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return AY_OK;
 }
