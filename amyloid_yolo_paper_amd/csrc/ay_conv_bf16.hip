@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, i
 //     pieces that copy zeros into a scratch KiB), so "stage g+1 has landed" is one constant `s_waitcnt vmcnt(PW)`.
 __device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];  // zero-initialised by the loader
 // AY_DBG&8: phase clock of the ring kernel, summed over workgroups (wave 0): [0] stage loops, [1] epilogues, [2] items,
-// [3] workgroups, [4] whole-kernel ticks per workgroup; 100 MHz ticks (s_memrealtime)
+// [3] workgroups, [4] whole-kernel ticks per workgroup, [5] first stages, [6] slowest workgroup; 100 MHz ticks (s_memrealtime)
 __device__ unsigned long long g_phase_ticks[8];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES>
@@ -848,6 +848,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         atomicAdd(&g_phase_ticks[3], 1ull);
         atomicAdd(&g_phase_ticks[4], wall_clock64() - tk_begin);
         atomicAdd(&g_phase_ticks[5], tk_s0);
+        atomicMax(&g_phase_ticks[6], wall_clock64() - tk_begin);
     }
 }
 
@@ -948,9 +949,9 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
         if (t[3])
-            fprintf(stderr, "[ay phase] k%d s%d BN%d tile%dx%d cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us (first stage %.2f of %d), epilogue %.2f us; wg total %.1f us\n",
+            fprintf(stderr, "[ay phase] k%d s%d BN%d tile%dx%d cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us (first stage %.2f of %d), epilogue %.2f us; wg total %.1f us (slowest %.1f)\n",
                     KS, STRIDE, BN, TH, TW, d->cin, d->cout, d->hout, residual ? 1 : 0, (double)t[2] / t[3], t[0] * 0.01 / t[2],
-                    t[5] * 0.01 / t[2], d->cin / (16 * NK), t[1] * 0.01 / t[2], t[4] * 0.01 / t[3]);
+                    t[5] * 0.01 / t[2], d->cin / (16 * NK), t[1] * 0.01 / t[2], t[4] * 0.01 / t[3], t[6] * 0.01);
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
     }

@@ -86,7 +86,9 @@ __device__ void bitonic_sort(P d, int n, int tid, int nthreads) {
     }
 }
 
-constexpr int NMS_LDS_KEYS = 4096;  // 32 KiB of keys sorted in LDS; larger candidate sets sort in the workspace
+constexpr int NMS_LDS_KEYS = 1024;  // 8 KiB of keys sorted in LDS (larger candidate sets sort in the workspace): with the 8-KiB alive mask the
+                                    // workgroup stays at 16 KiB of LDS, so it can share a CU with a persistent convolution workgroup of the next
+                                    // batch (117-144 KiB) instead of keeping 64 CUs away from it
 
 __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict__ pred, int N, int C, float nms_thres,
                                                         unsigned long long* keys, float* cand, int cap,
