@@ -18,9 +18,11 @@ from .utils import load_classes, non_max_suppression, rescale_boxes
 
 def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_path="weights/yolov3.weights",
            class_path=None, conf_thres=0.8, nms_thres=0.4, batch_size=1, n_cpu=0, img_size=416, precision="bf16",
-           rescale=True, verbose=True, device_ingest=True):
+           rescale=True, verbose=True, device_ingest=True, merge_boxes=False):
     """``device_ingest``: upload the decoded uint8 tiles and do /255 + pad-to-square + nearest resize on the GPU
-    (``ay_ingest_tiles_u8``, bit-identical to the host transforms); batches of mixed image sizes are ingested one size at a time."""
+    (``ay_ingest_tiles_u8``, bit-identical to the host transforms); batches of mixed image sizes are ingested one size at a time.
+    ``merge_boxes``: the reference's ``--merge_boxes True`` (``detect.py:131-133``): union-merge overlapping same-class boxes
+    after the rescale (``postprocess.merge_detections``)."""
     model = Darknet(model_def, img_size=img_size, precision=precision).to("cuda")
     if weights_path.endswith(".weights"):
         model.load_darknet_weights(weights_path)
@@ -54,6 +56,9 @@ def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_p
             if det is not None:
                 w, h = Image.open(path).size
                 rescale_boxes(det, img_size, (h, w))
+    if merge_boxes:
+        from .postprocess import merge_detections
+        results = [None if det is None else merge_detections(det) for det in results]
     return paths, results, classes
 
 
@@ -70,9 +75,11 @@ def main(argv=None):
     ap.add_argument("--img_size", type=int, default=416)
     ap.add_argument("--checkpoint_model", type=str)
     ap.add_argument("--precision", type=str, default="bf16")
+    ap.add_argument("--merge_boxes", type=str, default="False", help="merge overlapping boxes of the same class (reference detect.py:42)")
     opt = ap.parse_args(argv)
     paths, results, classes = detect(opt.image_folder, opt.model_def, opt.weights_path, opt.class_path, opt.conf_thres,
-                                     opt.nms_thres, opt.batch_size, opt.n_cpu, opt.img_size, opt.precision)
+                                     opt.nms_thres, opt.batch_size, opt.n_cpu, opt.img_size, opt.precision,
+                                     merge_boxes=opt.merge_boxes == "True")
     for path, det in zip(paths, results):
         print(f"Image: '{path}'")
         if det is None:

@@ -110,3 +110,27 @@ def iou_inputs(seed=3, n=257):
     c = a + rng.normal(0, 30, (n, 2)).astype(np.float32)
     b2 = np.concatenate([c, c + rng.uniform(1, 200, (n, 2)).astype(np.float32)], 1)
     return b1.astype(np.float32), b2.astype(np.float32)
+
+
+def merge_inputs():
+    """Inputs of the union-merge cases: name -> float32 [n,7] rows (x1,y1,x2,y2,conf,cls_conf,cls_pred)."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    out = {}
+    out["pair_overlap"] = np.array([[10.5, 10.2, 50.9, 40.1, .9, .8, 1], [30.0, 20.0, 80.0, 60.0, .7, .95, 1]], np.float32)
+    out["pair_disjoint"] = np.array([[10, 10, 20, 20, .9, .8, 1], [20.5, 10, 30, 20, .7, .9, 1]], np.float32)
+    out["touching_edge"] = np.array([[10, 10, 20, 20, .9, .8, 0], [20, 10, 30, 20, .7, .9, 0]], np.float32)
+    out["cross_class"] = np.array([[10, 10, 50, 50, .9, .8, 1], [20, 20, 60, 60, .7, .9, 0], [25, 25, 70, 70, .6, .9, 2],
+                                   [30, 30, 75, 75, .65, .9, 2]], np.float32)
+    out["chain3"] = np.array([[10, 10, 40, 40, .9, .8, 1], [35, 35, 70, 70, .8, .7, 1], [65, 65, 100, 100, .7, .6, 1]], np.float32)
+    out["degenerate"] = np.array([[10.2, 10.2, 10.9, 30.0, .9, .8, 1], [5, 5, 40, 40, .8, .7, 1], [100, 100, 99, 120, .5, .5, 0]], np.float32)
+    out["single"] = np.array([[1.5, 2.5, 30.5, 40.5, .9, .8, 0]], np.float32)
+    n = 40
+    xy = rng.uniform(0, 900, (n, 2))
+    wh = rng.uniform(10, 160, (n, 2))
+    det = np.concatenate([xy, xy + wh, rng.uniform(0.5, 1, (n, 2)), rng.integers(0, 2, (n, 1))], 1).astype(np.float32)
+    out["random40"] = det
+    n = 120
+    xy = rng.uniform(0, 1500, (n, 2))
+    wh = rng.uniform(8, 120, (n, 2))
+    out["random120_3class"] = np.concatenate([xy, xy + wh, rng.uniform(0.5, 1, (n, 2)), rng.integers(0, 3, (n, 1))], 1).astype(np.float32)
+    return out

@@ -144,3 +144,17 @@ def test_build_targets(golden_dir, case):
             np.testing.assert_array_equal(v, z[n])
         else:
             close(v, z[n], 1e-6)
+
+
+def test_merge_detections_vs_reference(golden_dir):
+    """postprocess.merge_detections against the reference's own mergeDetections outputs (tests/golden/merge_cases.npz,
+    generated by oracle/gen_golden_merge.py): same rows in the same order, exact."""
+    from amyloid_yolo_paper_amd.postprocess import merge_detections
+    z = load(golden_dir, "merge_cases")
+    for name, det in gc.merge_inputs().items():
+        got = merge_detections(torch.from_numpy(det))
+        got = got.reshape(-1, 7).numpy().astype(np.float64) if got.numel() else np.zeros((0, 7))
+        ref = z[name]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        np.testing.assert_array_equal(got, ref, err_msg=name)
+    assert z["chain3"].shape[0] == 1 and z["touching_edge"].shape[0] == 2 and z["random40"].shape[0] < 40
