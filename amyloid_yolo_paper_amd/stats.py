@@ -1,35 +1,45 @@
-"""Detection statistics on the host (reference ``utils/utils.py:71-190``): greedy TP matching, VOC-style AP.
-Small per-epoch bookkeeping on [n,7] rows; the IoUs come from the HIP box kernel."""
+"""Detection statistics (reference ``utils/utils.py:69-190``): greedy true-positive matching on the device
+(``ay_match_detections``), VOC-style AP per class on the host (a sort and two cumulative sums over the detections)."""
 import numpy as np
 import torch
 
-from .utils import bbox_iou
 
 
 def get_batch_statistics(outputs, targets, iou_threshold):
-    """outputs: list of [n,7] | None; targets [nT,6] (sample, class, x1, y1, x2, y2 in pixels) -> [[tp, conf, label]]"""
+    """Reference ``utils/utils.py:154-190``: outputs = list of [n,7] | None (what ``non_max_suppression`` returns), targets
+    [nT,6] = (sample, class, x1, y1, x2, y2 in pixels) -> [[true_positives, scores, labels]] per image with detections.
+    The greedy matching of the whole batch runs in one device kernel (``ay_match_detections``, one wavefront per image)."""
+    import ctypes as C
+
+    from . import _lib
+    from ._lib import check, ptr
+    from .utils import _to_dev
+    B = len(outputs)
+    present = [i for i, o in enumerate(outputs) if o is not None]
+    if not present:
+        return []
+    max_det = max(int(outputs[i].shape[0]) for i in present)
+    max_det = max(max_det, 1)
+    dev = _to_dev(torch.zeros(1)).device
+    rows = torch.zeros(B, max_det, 7, device=dev, dtype=torch.float32)
+    count = torch.zeros(B, device=dev, dtype=torch.int32)
+    for i in present:
+        n = int(outputs[i].shape[0])
+        rows[i, :n] = outputs[i].detach().to(device=dev, dtype=torch.float32)
+        count[i] = n
+    tg = torch.as_tensor(targets, dtype=torch.float32).to(dev).contiguous().reshape(-1, 6)
+    tp = torch.empty(B, max_det, device=dev, dtype=torch.float32)
+    ovf = torch.zeros(1, device=dev, dtype=torch.int32)
+    nT = int(tg.shape[0])
+    check(_lib.lib().ay_match_detections(ptr(rows), ptr(count), B, max_det, ptr(tg) if nT else None, nT, C.c_float(float(iou_threshold)),
+                                         ptr(tp), ptr(ovf), _lib.stream_ptr()), "ay_match_detections")
+    tp = tp.cpu().numpy()
+    if int(ovf.item()):
+        raise _lib.AyError("ay_match_detections: an image has more than 2048 targets")
     batch_metrics = []
-    for sample_i, output in enumerate(outputs):
-        if output is None:
-            continue
-        output = output.detach().cpu()
-        pred_boxes, pred_scores, pred_labels = output[:, :4], output[:, 4], output[:, -1]
-        true_positives = np.zeros(pred_boxes.shape[0])
-        annotations = targets[targets[:, 0] == sample_i][:, 1:]
-        target_labels = annotations[:, 0] if len(annotations) else []
-        if len(annotations):
-            detected = []
-            target_boxes = annotations[:, 1:]
-            for pred_i, (pred_box, pred_label) in enumerate(zip(pred_boxes, pred_labels)):
-                if len(detected) == len(annotations):
-                    break
-                if pred_label not in target_labels:
-                    continue
-                iou, box_index = bbox_iou(pred_box.unsqueeze(0), target_boxes).max(0)
-                if iou >= iou_threshold and box_index not in detected:
-                    true_positives[pred_i] = 1
-                    detected += [box_index]
-        batch_metrics.append([true_positives, pred_scores, pred_labels])
+    for i in present:
+        o = outputs[i].detach().cpu()
+        batch_metrics.append([tp[i, : o.shape[0]].astype(np.float64), o[:, 4], o[:, -1]])
     return batch_metrics
 
 

@@ -203,6 +203,14 @@ int ay_build_targets(const float* pred_boxes, const float* pred_cls, const float
 int ay_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, ay_stream_t stream);
 
+/* ---- evaluation statistics ------------------------------------------------------- */
+/* Greedy true-positive matching of get_batch_statistics (utils/utils.py:154-190) for a batch: rows [B][max_det][7]
+ * (x1,y1,x2,y2,conf,cls_conf,cls_pred, detections in descending-score order as non_max_suppression emits them), count[B],
+ * targets [nT][6] = (sample, class, x1, y1, x2, y2) in pixels -> tp [B][max_det] (1.0 = true positive).  *overflow is set
+ * to 1 if an image has more than 2048 targets (only the first 2048 are matched). */
+int ay_match_detections(const float* rows, const int32_t* count, int batch, int max_det, const float* targets, int n_targets,
+                        float iou_thres, float* tp, int32_t* overflow, ay_stream_t stream);
+
 /* ---- tile ingest ----------------------------------------------------------------- */
 /* uint8 HWC RGB tiles [B,H,W,3] -> float32 NCHW [B,3,S,S]: x/255 (utils/transforms.py:96), centre zero pad to square
  * (utils/datasets.py:22-32), nearest resize src = min(floor(dst * (float)in/out), in-1) (utils/datasets.py:35-37), one pass. */

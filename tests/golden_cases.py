@@ -134,3 +134,35 @@ def merge_inputs():
     wh = rng.uniform(8, 120, (n, 2))
     out["random120_3class"] = np.concatenate([xy, xy + wh, rng.uniform(0.5, 1, (n, 2)), rng.integers(0, 3, (n, 1))], 1).astype(np.float32)
     return out
+
+
+def stats_inputs(seed=55, B=12, C=3, size=416.0):
+    """Evaluation-statistics case: per image a list of [n,7] detections (or None) in descending-score order
+    and targets [nT,6] = (sample, class, x1, y1, x2, y2) in pixels; detections are jittered copies of some targets (true
+    positives at various IoUs, duplicates of the same target, wrong classes) plus random boxes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    outputs, targets = [], []
+    for b in range(B):
+        nt = int(rng.integers(1, 14)) if b != 1 else 0          # image 1 has no targets
+        xy = rng.uniform(0, size - 80, (nt, 2))
+        wh = rng.uniform(20, 80, (nt, 2))
+        cls = rng.integers(0, C, nt)
+        tb = np.concatenate([xy, xy + wh], 1)
+        for k in range(nt):
+            targets.append([b, cls[k], *tb[k]])
+        if b == 3:
+            outputs.append(None)                                 # image 3 has no detections
+            continue
+        rows = []
+        for k in range(nt):
+            for _ in range(int(rng.integers(0, 4))):             # 0..3 detections near each target
+                jit = rng.normal(0, rng.choice([1.0, 3.0, 8.0, 25.0]), 4)
+                c = cls[k] if rng.uniform() < 0.8 else (cls[k] + 1) % C
+                rows.append([*(tb[k] + jit), rng.uniform(0.5, 1), rng.uniform(0.5, 1), c])
+        for _ in range(int(rng.integers(1, 6))):                 # unrelated boxes
+            p = rng.uniform(0, size - 60, 2)
+            rows.append([*p, *(p + rng.uniform(15, 60, 2)), rng.uniform(0.5, 1), rng.uniform(0.5, 1), rng.integers(0, C)])
+        rows = np.asarray(rows, np.float32)
+        rows = rows[np.argsort(-(rows[:, 4] * rows[:, 5]), kind="stable")]
+        outputs.append(rows)
+    return outputs, np.asarray(targets, np.float32).reshape(-1, 6)

@@ -453,3 +453,45 @@ def test_resblock_fused_kernel(dev, case):
     err = (got.cpu() - ref).abs()
     bound = ref.abs() * 2.0 ** -6 + 2e-3   # two rounded layers: the intermediate may round the other way too
     assert float((err > bound).float().mean()) <= 1e-3, (float((err > bound).float().mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_eval_statistics_device_vs_reference(golden_dir, dev, thr):
+    """stats.get_batch_statistics (ay_match_detections) + ap_per_class against the reference's outputs: TP flags exact,
+    precision / recall / AP / F1 to 1e-12."""
+    from amyloid_yolo_paper_amd import stats
+    z = load(golden_dir, "stats_cases")
+    tag = f"t{int(thr * 100)}"
+    outputs, targets = gc.stats_inputs()
+    t_out = [None if o is None else torch.from_numpy(o) for o in outputs]
+    metrics = stats.get_batch_statistics(t_out, torch.from_numpy(targets), thr)
+    assert len(metrics) == int(z[f"{tag}_n"])
+    for k, (tp, scores, labels) in enumerate(metrics):
+        np.testing.assert_array_equal(tp, z[f"{tag}_tp{k}"])
+        np.testing.assert_array_equal(scores.numpy(), z[f"{tag}_scores{k}"])
+        np.testing.assert_array_equal(labels.numpy(), z[f"{tag}_labels{k}"])
+    tp, scores, labels = [np.concatenate([np.asarray(v) for v in x], 0) for x in zip(*metrics)]
+    p, r, ap, f1, cls = stats.ap_per_class(tp, scores, labels, targets[:, 1].tolist())
+    for got, name in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1")):
+        np.testing.assert_allclose(got, z[f"{tag}_{name}"], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(cls, z[f"{tag}_cls"])
+    # against the oracle on a bigger random case (ties in IoU included: duplicated targets)
+    rng = np.random.Generator(np.random.PCG64(3))
+    B = 9
+    tg, outs = [], []
+    for b in range(B):
+        nt = int(rng.integers(20, 120))
+        xy = rng.uniform(0, 900, (nt, 2))
+        tb = np.concatenate([xy, xy + rng.uniform(10, 90, (nt, 2))], 1)
+        tb[nt // 2] = tb[0]                                       # exact duplicate target: equal IoUs, first index wins
+        cls_ = rng.integers(0, 2, nt)
+        tg += [[b, cls_[k], *tb[k]] for k in range(nt)]
+        nd = int(rng.integers(50, 300))
+        pick = rng.integers(0, nt, nd)
+        rows = np.concatenate([tb[pick] + rng.normal(0, 6, (nd, 4)), rng.uniform(0.5, 1, (nd, 2)), cls_[pick][:, None]], 1)
+        outs.append(rows.astype(np.float32))
+    tg = np.asarray(tg, np.float32)
+    ref = bo.get_batch_statistics(outs, tg, 0.5)
+    got = stats.get_batch_statistics([torch.from_numpy(o) for o in outs], torch.from_numpy(tg), 0.5)
+    for (a, _, _), (b_, _, _) in zip(got, ref):
+        np.testing.assert_array_equal(a, b_)

@@ -158,3 +158,21 @@ def test_merge_detections_vs_reference(golden_dir):
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         np.testing.assert_array_equal(got, ref, err_msg=name)
     assert z["chain3"].shape[0] == 1 and z["touching_edge"].shape[0] == 2 and z["random40"].shape[0] < 40
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_eval_statistics_oracle_vs_reference(golden_dir, thr):
+    """oracle get_batch_statistics / ap_per_class against the reference's outputs (tests/golden/stats_cases.npz)"""
+    z = load(golden_dir, "stats_cases")
+    tag = f"t{int(thr * 100)}"
+    outputs, targets = gc.stats_inputs()
+    metrics = bo.get_batch_statistics(outputs, targets, thr)
+    assert len(metrics) == int(z[f"{tag}_n"])
+    for k, (tp, scores, labels) in enumerate(metrics):
+        np.testing.assert_array_equal(tp, z[f"{tag}_tp{k}"])
+        np.testing.assert_array_equal(scores, z[f"{tag}_scores{k}"])
+    tp, scores, labels = [np.concatenate(x, 0) for x in zip(*metrics)]
+    p, r, ap, f1, cls = bo.ap_per_class(tp, scores, labels, targets[:, 1])
+    for got, name in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1")):
+        np.testing.assert_allclose(got, z[f"{tag}_{name}"], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(cls, z[f"{tag}_cls"])
