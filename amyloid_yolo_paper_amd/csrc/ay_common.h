@@ -55,6 +55,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
                  : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                  : "memory");
 }
+// 4-byte variant (global_load_lds_dword): lane l copies 4 B from its own `gsrc` to LDS byte address `lds_addr + 4*l`;
+// for sources that are only 4-byte aligned (fp32 image rows at arbitrary column offsets).
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                 : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }

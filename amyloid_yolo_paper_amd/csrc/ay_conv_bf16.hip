@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, i
         for (int s = 0; s < nstages; ++s) {
             const bool last_stage = (s + 1 == nstages);
             const bool more = !last_stage || has_next;
-            if (!(a.dbg & 1)) {
+            if (!AY_DBGBIT(a, 1)) {
                 if (!last_stage) {
                     load_pixels(s + 1);
                     dma_filters(s + 1, cur ^ 1);
@@ -541,10 +541,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, i
                 for (int n = 0; n < NT; ++n)
                     fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
             };
-            if (!(a.dbg & 2)) load_frags(0, af[0], bfr[0]);
+            if (!AY_DBGBIT(a, 2)) load_frags(0, af[0], bfr[0]);
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {
-                if (a.dbg & 2) break;
+                if (AY_DBGBIT(a, 2)) break;
                 if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
@@ -742,7 +742,8 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
 
     int cur = 0;  // ring slot of the stage the MFMAs read
     int par = 0;  // scale/shift region of the item the MFMAs work on
-    const bool clk = (a.dbg & 8) && tid == 0;
+    // phase clock (instrumented build only, see AY_DBGBIT): wave-uniform tick counters
+    const bool clk = AY_DBGBIT(a, 8) && wave == 0;
     unsigned long long tk_stage = 0, tk_epi = 0, tk_items = 0, tk0 = 0, tk_begin = 0, tk_s0 = 0;
     if (clk) tk_begin = wall_clock64();
     while (true) {
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             // the PW DMA pieces of stage g+NBUF-1 are issued one by one behind the MFMA groups of this stage (an LDS-DMA
             // issue costs the wave 60-180 cycles; behind 4-8 queued MFMAs it is hidden, in a burst at the stage start
             // both waves of a SIMD pay it at the same time)
-            const bool issued = !ld_done && !(a.dbg & 1);
+            const bool issued = !ld_done && !AY_DBGBIT(a, 1);
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
@@ -788,11 +789,11 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 for (int n = 0; n < NT; ++n)
                     fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
             };
-            if (!(a.dbg & 2)) load_frags(0, af[0], bfr[0]);
+            if (!AY_DBGBIT(a, 2)) load_frags(0, af[0], bfr[0]);
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {
-                if (a.dbg & 2) break;
-                if (t + 1 < NSTEP && !(a.dbg & 64)) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
+                if (AY_DBGBIT(a, 2)) break;
+                if (t + 1 < NSTEP && !AY_DBGBIT(a, 64)) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 // (unequal priorities for the two waves of a SIMD were measured slower: 21.4 vs 20.0 us compute-only)
                 __builtin_amdgcn_s_setprio(1);
@@ -831,7 +832,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             tk_stage += t - tk0;
             tk0 = t;
         }
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4)>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                        reinterpret_cast<const float*>(lds + SS_BASE + par * 1024));
         if (clk) {
             tk_epi += wall_clock64() - tk0;
@@ -841,7 +842,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         item = next_item;
         par = (par + 1) & 3;
     }
-    if (clk) {
+    if (clk && lane == 0) {
         atomicAdd(&g_phase_ticks[0], tk_stage);
         atomicAdd(&g_phase_ticks[1], tk_epi);
         atomicAdd(&g_phase_ticks[2], tk_items);

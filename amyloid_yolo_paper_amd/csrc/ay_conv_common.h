@@ -2,6 +2,15 @@
 #pragma once
 #include "ay_common.h"
 
+// Timing-experiment hooks (AY_DBG bits: 1 no staging, 2 no MFMA phase, 4 no output stores, 8 phase clock, 64 MFMA-only) exist
+// only in a library built with -DAY_PHASE_CLOCK (AY_PHASE_CLOCK=1 python build.py).  In the product build AY_DBGBIT() is a
+// compile-time 0: run-time branches inside the unrolled MFMA loops cost the register-saturated kernels 20-30 VGPRs of spills.
+#ifdef AY_PHASE_CLOCK
+#define AY_DBGBIT(a, bit) ((a).dbg & (bit))
+#else
+#define AY_DBGBIT(a, bit) 0
+#endif
+
 namespace ay {
 
 struct ConvArgs {
@@ -59,9 +68,9 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 }
 
 // RES_INLINE: the residual is loaded here, one 32-pixel block ahead of its use (large wave tiles cannot hold all of it).
-// ss_lds != nullptr: per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift],
+// SS_MODE 1|2 (ss_lds != nullptr; 0 = from global memory): per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift],
 // so the epilogue issues no vector-memory loads that would have to wait behind its own stores.
-template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false>
+template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
                                               int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr) {
     const int CP = a.cout_pad;
@@ -109,7 +118,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 float v[4], w[4];
                 {
                     float4 s0, t0, s1, t1;
-                    if (ss_lds) {
+                    if constexpr (SS_MODE == 2) {
+                        // explicit LDS address space: through a generic pointer the compiler may emit flat loads, which
+                        // count on vmcnt too and make it wait for every LDS-DMA in flight (seen in the fused stem)
+                        typedef __attribute__((address_space(3))) const f32x4 lds_f4;
+                        lds_f4* sl = (lds_f4*)(__attribute__((address_space(3))) const float*)ss_lds;
+                        const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;  // multiple of 4 floats
+                        const f32x4 a0 = sl[l0 >> 2], b0 = sl[(128 + l0) >> 2], a1 = sl[(l0 + 8) >> 2], b1 = sl[(128 + l0 + 8) >> 2];
+                        s0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                        t0 = make_float4(b0[0], b0[1], b0[2], b0[3]);
+                        s1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                        t1 = make_float4(b1[0], b1[1], b1[2], b1[3]);
+                    } else if (ss_lds) {  // SS_MODE 1: LDS through the generic pointer, run-time test kept (resolves to ds_read in the
+                                          // ring kernels; the code shape matters there: they sit at 256 VGPRs without a spill)
                         const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;
                         s0 = *reinterpret_cast<const float4*>(ss_lds + l0);
                         t0 = *reinterpret_cast<const float4*>(ss_lds + 128 + l0);
@@ -171,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                         auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
                         // plain stores: `nt` (streaming) stores were measured slower -- their completion, which the next stage's
                         // counted DMA wait sits behind, takes longer (first stage of the next item 4.0 -> 5.1 us)
-                        if (ok && !(a.dbg & 4)) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        if (ok && !AY_DBGBIT(a, 4)) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                     }
                 }
             }

@@ -13,6 +13,19 @@
 
 namespace ay {
 
+__device__ __attribute__((aligned(64))) uint32_t g_zero_page_st[16];
+#ifdef AY_PHASE_CLOCK
+__device__ unsigned long long g_stem_ticks[8];  // [0] DMA issue, [1] phase B, [2] barrier, [3] phase C, [4] epilogue, [5] tail wait, [6] items
+#define STEM_TICK(k)                                   \
+    if (wave == 0) {                                   \
+        const unsigned long long t_ = wall_clock64();  \
+        tk[k] += t_ - tk_last;                         \
+        tk_last = t_;                                  \
+    }
+#else
+#define STEM_TICK(k)
+#endif
+
 struct StemFusedArgs {
     const float* x;         // [B][3][H][W] f32
     const uint16_t* w0;     // stem filters, bf16 [32 cout][32 k], k = ci*9 + kh*3 + kw (27..31 zero)
@@ -32,19 +45,21 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
     constexpr int IH = SH + 2, IW = SW + 2;               // 19 x 67 image pixels
     constexpr int IMG_ELEMS = 3 * IH * IW;                // 3819
     constexpr int NT_ = 1024;                                // threads
-    constexpr int NIMG = (IMG_ELEMS + NT_ - 1) / NT_;     // 4 prefetch registers per thread
+    constexpr int IMG_DMAS = (IMG_ELEMS + 63) / 64;       // 60 wave-wide 4-byte DMA instructions per image tile
+    constexpr int IMG_BYTES = IMG_DMAS * 256;             // 15360
+    constexpr int NDMA = (IMG_DMAS + 15) / 16;            // 4 per wave (waves past the end copy zeros into a scratch line)
+    constexpr int NIB = 3;                                // image-tile ring: tiles of items i, i+1, i+2
     constexpr int SLAB = 2 * S_PIXP * 16;                 // one 16-channel chunk of stem output
     constexpr int W1_BYTES = 2 * 9 * 2 * BN * 16;         // 36864
-    constexpr int OFF_IMG = 0;
-    constexpr int OFF_STEM = ((IMG_ELEMS * 4 + 15) / 16) * 16;
+    constexpr int OFF_STEM = NIB * IMG_BYTES + 256;       // + 256-byte scratch line for the padding DMAs
     constexpr int OFF_W1 = OFF_STEM + 2 * SLAB;
     constexpr int OFF_SS0 = OFF_W1 + W1_BYTES;
-    constexpr int LDS_BYTES = OFF_SS0 + 256;
+    constexpr int OFF_SS1 = OFF_SS0 + 256;                // layer-1 [scale 64 | pad to 128][shift] floats (conv_epilogue's LDS form):
+    constexpr int LDS_BYTES = OFF_SS1 + 1024;             // no global loads in the loop, whose waits would drain the tile DMAs
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     constexpr int MT = 1, NT = 1;                         // wave tile 32 channels x 32 pixels: waves = 2 (channels) x 8 (rows)
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
-    float* img = reinterpret_cast<float*>(lds + OFF_IMG);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,39 +82,50 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
     bf16x8 wa[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) wa[ks] = *reinterpret_cast<const bf16x8*>(s.w0 + c * 32 + 16 * ks + 8 * hh);
+    asm volatile("" ::"v"(wa[0]), "v"(wa[1]));  // complete these loads here: a wait at their first use inside the loop would be
+                                                 // executed every item and drain the tile DMAs with it
 
-    // per-lane constants of the stem MFMA: image-tile offset of k = 16*ks + 8*hh + e (-1: zero padding of K), affine
-    int koff[2][8];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * ks + 8 * hh + e;
-            koff[ks][e] = k < 27 ? ((k / 9) * IH + (k % 9) / 3) * IW + k % 3 : -1;
-        }
+    // image-tile offset of K index k = 16*ks + 8*hh + e (-1: zero padding of K): a compile-time constant per (ks, e) and lane
+    // half, selected by hh at the use (a register table of 16 entries per lane pushed the 128-VGPR budget into scratch, and
+    // scratch reloads wait vmcnt(0), which drains the tile DMAs)
+    auto koff = [](int k) constexpr { return k < 27 ? ((k / 9) * IH + (k % 9) / 3) * IW + k % 3 : -1; };
     // stem scale/shift: [scale 32][shift 32] floats in LDS (32 registers otherwise; 16 waves leave 128 per lane)
     float* ss0 = reinterpret_cast<float*>(lds + OFF_SS0);
     if (tid < 32) {
         ss0[tid] = s.scale0[tid];
         ss0[32 + tid] = s.shift0[tid];
     }
+    if (tid < BN) {
+        float* ss1 = reinterpret_cast<float*>(lds + OFF_SS1);
+        ss1[tid] = a.scale[tid];
+        ss1[128 + tid] = a.shift[tid];
+    }
 
-    float rimg[NIMG];
-    auto load_image = [&](int it) {
-        const int pt = it;  // one channel group: item == pixel tile
-        const int b = pt / tiles_per_img;
-        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
+    // image tiles go global -> LDS by 4-byte LDS-DMA (fp32 rows start at arbitrary column offsets), two items ahead, into a ring
+    // of three tile buffers: nothing is staged in registers and an HBM round trip has two whole items to complete (with the
+    // register prefetch of one item the kernel sat at ~2 us of exposed latency per item).  Pixels outside the image come from a
+    // page of zeros; every wave issues NDMA instructions per tile so the waits below are counted.
+    const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_zero_page_st);
+    const unsigned lds_base = lds_addr_of(lds);
+    auto issue_image = [&](int it, int slot_i) __attribute__((always_inline)) {
+        const int b = it / tiles_per_img;
+        const int y0 = ((it / a.tiles_x) % a.tiles_y) * TH, x0 = (it % a.tiles_x) * TW;
         const float* xb = s.x + (size_t)b * 3 * s.H * s.W;
-#pragma unroll
-        for (int i = 0; i < NIMG; ++i) {
-            const int u = i * NT_ + tid;
-            float v = 0.f;
-            if (u < IMG_ELEMS) {
-                const int col = u % IW, r = (u / IW) % IH, ci = u / (IW * IH);
-                const int iy = 2 * y0 - 2 + r, ix = 2 * x0 - 2 + col;
-                if (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) v = xb[((size_t)ci * s.H + iy) * s.W + ix];
+#pragma unroll 1
+        for (int i = 0; i < NDMA; ++i) {  // not unrolled: one set of address temporaries
+            const int k = i * 16 + wave;  // wave-uniform
+            const void* g = zero_page + (lane & 15) * 4;
+            int dst = NIB * IMG_BYTES;    // scratch line
+            if (k < IMG_DMAS) {
+                const int u = k * 64 + lane;
+                if (u < IMG_ELEMS) {
+                    const int col = u % IW, r = (u / IW) % IH, ci = u / (IW * IH);
+                    const int iy = 2 * y0 - 2 + r, ix = 2 * x0 - 2 + col;
+                    if (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) g = xb + ((size_t)ci * s.H + iy) * s.W + ix;
+                }
+                dst = slot_i * IMG_BYTES + k * 256;
             }
-            rimg[i] = v;
+            dma4(g, lds_base + dst);
         }
     };
 
@@ -108,29 +134,39 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
     const int pb = (hh * S_PIXP + (wn * 2) * SW + c * 2) * 16;  // pixel (ty = wn, tx = c) -> stem pixel (2ty, 2tx)
     const int wa1 = OFF_W1 + (hh * BN + wm * 32 + c) * 16;
 
-    load_image(item);
+    issue_image(item, 0);
+    {
+        const int it1 = item + slots;
+        if (it1 < last) {
+            issue_image(it1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();  // tile 0 landed; filters and scale/shift tables written
+    int ib = 0;
+#ifdef AY_PHASE_CLOCK
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_last = wall_clock64();
+#endif
     while (true) {
         const int pt = item;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
         const int next_item = item + slots;
         const bool has_next = next_item < last;
-
-        // ---- A: image tile -> LDS ----------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < NIMG; ++i) {
-            const int u = i * NT_ + tid;
-            if (u < IMG_ELEMS) img[u] = rimg[i];
-        }
-        __syncthreads();
-        if (has_next) load_image(next_item);  // in flight during B, C, D
+        const bool has_next2 = next_item + slots < last;
+        const float* img = reinterpret_cast<const float*>(lds + ib * IMG_BYTES);
+        // tile of item i+2 -> the buffer item i-1 read (every wave has passed two barriers since)
+        if (has_next2) issue_image(next_item + slots, ib >= 1 ? ib - 1 : NIB - 1);
+        STEM_TICK(0)
 
         // ---- B: stem by MFMA into the slabs ----------------------------------------------------------------
         for (int blk = wave; blk < S_PIXP / 32; blk += 16) {
             const int P = blk * 32 + c;
             const int sy = P / SW, sx = P % SW;  // stem pixel inside the halo tile (P >= S_PIX: padding rows of the slab)
             const bool inside = P < S_PIX;
-            const float* ip = img + (inside ? sy * IW + sx : 0);
+            const int ibase = inside ? sy * IW + sx : 0;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -139,10 +175,12 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
                 unsigned pk[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int o0 = koff[ks][2 * jj], o1 = koff[ks][2 * jj + 1];
-                    const float v0 = o0 >= 0 ? ip[o0] : 0.f;
-                    const float v1 = o1 >= 0 ? ip[o1] : 0.f;
-                    pk[jj] = pack2bf(v0, v1);
+                    // K entries past 27 read the tile buffer's zero tail (filled from the zero page): unconditional loads, the
+                    // select is on the index (a load under a lane-dependent condition costs an exec-mask round trip each)
+                    auto idx = [&](int k) { return koff(k) >= 0 ? ibase + koff(k) : IMG_ELEMS; };
+                    const int i0 = hh ? idx(16 * ks + 8 + 2 * jj) : idx(16 * ks + 2 * jj);
+                    const int i1 = hh ? idx(16 * ks + 8 + 2 * jj + 1) : idx(16 * ks + 2 * jj + 1);
+                    pk[jj] = pack2bf(img[i0], img[i1]);
                 }
                 const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], __builtin_bit_cast(bf16x8, pv), acc, 0, 0, 0);
@@ -168,7 +206,11 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
                 *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
         }
-        __syncthreads();
+        STEM_TICK(1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barriers: __syncthreads would drain the DMAs (vmcnt(0))
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STEM_TICK(2)
 
         // ---- C: layer 1, 2 chunks x 9 taps ------------------------------------------------------------------
         f32x16 acc1[MT][NT];
@@ -190,13 +232,42 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
                 for (int m = 0; m < MT; ++m) acc1[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc1[m][0], 0, 0, 0);
             }
         }
+        STEM_TICK(3)
         // ---- D: epilogue ----------------------------------------------------------------------------------
         ResRegs<MT, NT> rr;
-        conv_epilogue<BN, MT, NT, TW, false, false>(a, acc1, rr, b, 0, wm, wn, c, hh, y0, x0);
+        conv_epilogue<BN, MT, NT, TW, false, false, false, 2>(a, acc1, rr, b, 0, wm, wn, c, hh, y0, x0,
+                                                              reinterpret_cast<const float*>(lds + OFF_SS1));
+        STEM_TICK(4)
+#ifdef AY_PHASE_CLOCK
+        if (wave == 0) ++tk[6];
+#endif
         if (!has_next) break;
-        __syncthreads();  // everyone is done reading the slabs / image before the next item overwrites them
+        // tile i+1 has landed: in issue order this wave's younger operations are the DMAs of tile i+2 (if any) and the two
+        // output stores of this item (none if its pixel row lies outside the image); everyone is done reading the slabs
+        {
+            const bool stored = (y0 + wn) < a.hout;
+            if (has_next2) {
+                if (stored)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA + 2) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            } else {
+                if (stored)
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STEM_TICK(5)
         item = next_item;
+        ib = ib + 1 == NIB ? 0 : ib + 1;
     }
+#ifdef AY_PHASE_CLOCK
+    if (wave == 0 && lane == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_stem_ticks[k], tk[k]);
+#endif
 }
 
 }  // namespace ay
@@ -242,5 +313,16 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     dim3 grid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
     AY_CHECK_LAUNCH("stem_s2_fused_kernel");
+#ifdef AY_PHASE_CLOCK
+    if (getenv("AY_DBG") && (atoi(getenv("AY_DBG")) & 8)) {
+        unsigned long long t[8] = {0}, z[8] = {0};
+        (void)hipStreamSynchronize(S(stream));
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stem_ticks), sizeof(t));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stem_ticks), z, sizeof(z));
+        if (t[6])
+            fprintf(stderr, "[ay stem] per item (us): dma issue %.2f, stem MFMA %.2f, barrier %.2f, layer-1 MFMA %.2f, epilogue %.2f, tail wait %.2f\n",
+                    t[0] * 0.01 / t[6], t[1] * 0.01 / t[6], t[2] * 0.01 / t[6], t[3] * 0.01 / t[6], t[4] * 0.01 / t[6], t[5] * 0.01 / t[6]);
+    }
+#endif
     return AY_OK;
 }
