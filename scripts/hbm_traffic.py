@@ -27,8 +27,11 @@ fam_bytes, fam_n = 0.0, 0
 print("layer                          fetch MB (x2)  write MB | algorithmic: in MB  out MB  residual MB | fetch/(in+res)")
 for (n, fv), (n2, wv) in zip(fs, ws):
     assert n == n2
-    if "conv_bf16" in n or "stem" in n:
+    if "conv_bf16" in n or "stem" in n or "resblock" in n:
         i, e = convs[ci]; ci += 1
+        if "resblock" in n:  # 1x1 + 3x3 + shortcut in one kernel: x in, out out, the 1x1's output never leaves the CU
+            i, e1 = convs[ci]; ci += 1
+            e = dict(e1, cin=e["cin"], fuse_into_shortcut=False)
         fused_stem = "stem_s2_fused" in n   # layers 0 and 1 in one kernel: fp32 image in, layer-1 output out
         if fused_stem:
             i, e = convs[ci]; ci += 1
