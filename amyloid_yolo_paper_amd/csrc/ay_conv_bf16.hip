@@ -18,6 +18,8 @@
 //   LDS filters  [kstep][tap][half][BN][8 bf16]
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ay_conv_common.h"
 
 namespace ay {
@@ -581,6 +583,8 @@ __device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];  // zero-initi
 // AY_DBG&8: phase clock of the ring kernel, summed over workgroups (wave 0): [0] stage loops, [1] epilogues, [2] items,
 // [3] workgroups, [4] whole-kernel ticks per workgroup, [5] first stages, [6] slowest workgroup; 100 MHz ticks (s_memrealtime)
 __device__ unsigned long long g_phase_ticks[8];
+// dynamic item dealing: 64 rotating sets of {8 per-XCD item counters, exit counter}; zero at load, reset by the last workgroup
+__device__ unsigned g_deal[64][16];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
@@ -603,7 +607,8 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     constexpr int DUMMY_BASE = NBUF * BUF_BYTES;
     constexpr int SS_BASE = DUMMY_BASE + 1024;              // 4 x 1 KiB [scale 128][shift 128], by item index & 3 (the loader
                                                             // runs at most NBUF-1 <= 2 items ahead of the epilogue)
-    constexpr int LDS_BYTES = NBUF * BUF_BYTES + 5 * 1024;
+    constexpr int MBOX_BASE = NBUF * BUF_BYTES + 5 * 1024;  // 8 ints: item ids by sequence number & 7
+    constexpr int LDS_BYTES = MBOX_BASE + 64;
     static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
     static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
     static_assert((KK2 * 2 * BN * 16) % 1024 == 0, "filter slab is whole DMA pieces");
@@ -623,7 +628,37 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     const int first = xcd * per_xcd;
     const int last = min(first + per_xcd, n_items);
     int item = first + slot;
-    if (item >= last) return;
+    // ---- item dealing --------------------------------------------------------------------------------------------
+    // A workgroup's first item is static; the following ones come from its XCD's atomic counter (a.deal), so that a slow
+    // CU (HBM channel luck, a neighbour kernel on the CU) simply takes fewer items instead of setting the kernel time.
+    // Item ids travel through an 8-entry LDS mailbox indexed by sequence number: thread 0 fetches id[c+D] at the start of the
+    // epilogue of item c (the atomic's latency hides under it) and posts it at its end; the stage barriers publish it long
+    // before the loader (at most 2 item boundaries ahead) or the MFMA side need it.  Without counters the same mailbox
+    // carries the static ids.
+    const bool dyn = a.deal != nullptr;
+    auto leave = [&]() __attribute__((always_inline)) {
+        if (dyn && tid == 0) {
+            const unsigned d = atomicAdd(a.deal + 8, 1u);
+            if (d == gridDim.x - 1) {  // last workgroup out: hand the counter set back zeroed
+#pragma unroll
+                for (int i = 0; i < 9; ++i) atomicExch(a.deal + i, 0u);
+            }
+        }
+    };
+    if (item >= last) {
+        leave();
+        return;
+    }
+    volatile int* mbox = reinterpret_cast<volatile int*>(lds + MBOX_BASE);
+    const int D = (a.cin / (16 * NK)) >= 2 ? 3 : 5;  // fetch-ahead distance in items
+    auto fetch_id = [&](int prev) __attribute__((always_inline)) -> int {  // thread 0 only
+        if (prev >= last) return last;
+        return dyn ? first + D * slots + (int)atomicAdd(a.deal + xcd, 1u) : prev + slots;
+    };
+    if (tid < D) mbox[tid] = min(item + tid * slots, last);  // the first D items of a workgroup are static (no atomics, no
+                                                             // wait in the prologue); id[c+D] is posted by the epilogue of item c
+    __syncthreads();  // ids 0..D-1 posted (a single-stage item makes the loader ask for id 1 already in the prologue below)
+    int seq_l = 0, seq_c = 0;  // sequence numbers of the loader's / the MFMA side's current item
 
     const size_t in_plane = (size_t)a.hin * a.win * 32;
     const int CP = a.cout_pad;
@@ -697,7 +732,8 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         if (++ld_s == a.cin / (16 * NK)) {
             ld_s = 0;
             ld_par = (ld_par + 1) & 3;
-            ld_item += slots;
+            ++seq_l;
+            ld_item = __builtin_amdgcn_readfirstlane(mbox[seq_l & 7]);
             if (ld_item < last)
                 setup_loader(ld_item);
             else
@@ -752,7 +788,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
-        const int next_item = item + slots;
+        const int next_item = __builtin_amdgcn_readfirstlane(mbox[(seq_c + 1) & 7]);
         const bool has_next = next_item < last;
 
         f32x16 acc[MT][NT];
@@ -832,16 +868,24 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             tk_stage += t - tk0;
             tk0 = t;
         }
+        int fetched = last;
+        if (tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
         conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                        reinterpret_cast<const float*>(lds + SS_BASE + par * 1024));
+        if (tid == 0) {
+            mbox[(seq_c + D) & 7] = fetched;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if (clk) {
             tk_epi += wall_clock64() - tk0;
             ++tk_items;
         }
         if (!has_next) break;
         item = next_item;
+        ++seq_c;
         par = (par + 1) & 3;
     }
+    leave();
     if (clk && lane == 0) {
         atomicAdd(&g_phase_ticks[0], tk_stage);
         atomicAdd(&g_phase_ticks[1], tk_epi);
@@ -904,6 +948,17 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     a.dbg = dbg;
     static const int stagger = getenv("AY_STAGGER") ? atoi(getenv("AY_STAGGER")) : 0;
     a.stagger = stagger;
+    a.deal = nullptr;
+    if (V2 && conv_mode() >= 4) {
+        static const int dynamic = getenv("AY_DYNAMIC") ? atoi(getenv("AY_DYNAMIC")) : 1;
+        static unsigned* deal_base = nullptr;
+        static std::atomic<unsigned> deal_seq{0};
+        if (dynamic && !deal_base) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_deal)) == hipSuccess) deal_base = (unsigned*)p;
+        }
+        if (dynamic && deal_base) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
+    }
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);

@@ -26,6 +26,7 @@ struct ConvArgs {
     int dbg;  // timing experiments only (AY_DBG): 1 = no staging in the stage loop, 2 = no MFMA phase
     int stagger;  // ring kernel: start workgroup (slot & 3) after slot&3 x stagger x ~4 us, so that the CUs' epilogue
                   // (HBM) phases do not coincide
+    unsigned* deal;  // ring kernel: per-launch work counters (8 per-XCD item counters + 1 exit counter), nullptr = static dealing
 };
 
 // ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
@@ -81,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     // residual of (n, m) 32x32 blocks, loaded RD blocks ahead of their use: a load issued only one block (~150 cycles)
     // ahead exposes nearly the whole memory latency on every block; the MFMA fragment registers are dead here, so the
     // deeper ring costs no extra registers
-    constexpr int RD = (MT * NT >= 4) ? 3 : MT * NT;
+    constexpr int RD = (MT * NT >= 4) ? 2 : MT * NT;
     uint4 rres[RD][2];
     auto load_res = [&](int t, uint4 (&r)[2]) __attribute__((always_inline)) {
         const int n = t / MT, m = t % MT;
