@@ -616,6 +616,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    // base priority 2, MFMA groups 3: a latency-bound neighbour on the CU (the merge-NMS wavefront of the previous batch runs at
+    // priority 0) only gets the issue slots these waves leave free
+    __builtin_amdgcn_s_setprio(2);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -832,13 +835,13 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 if (t + 1 < NSTEP && !AY_DBGBIT(a, 64)) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 // (unequal priorities for the two waves of a SIMD were measured slower: 21.4 vs 20.0 us compute-only)
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (issued) {
 #pragma unroll

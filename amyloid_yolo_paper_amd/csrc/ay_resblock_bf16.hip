@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
     static_assert(MT * WM * 32 == BN2 && NT * WN * 32 == TH * TW, "tile split");
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    __builtin_amdgcn_s_setprio(2);  // above a co-resident merge-NMS wavefront (priority 0)
     const ConvArgs& a = s.c2;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -297,13 +298,13 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             for (int t = 0; t < 9; ++t) {
                 if (t + 1 < 9) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (issued) {
 #pragma unroll

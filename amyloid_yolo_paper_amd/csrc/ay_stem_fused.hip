@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
     constexpr int MT = 1, NT = 1;                         // wave tile 32 channels x 32 pixels: waves = 2 (channels) x 8 (rows)
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    __builtin_amdgcn_s_setprio(2);  // above a co-resident merge-NMS wavefront (priority 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
