@@ -960,7 +960,9 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             void* p = nullptr;
             if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_deal)) == hipSuccess) deal_base = (unsigned*)p;
         }
-        if (dynamic && deal_base) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
+        // 3x3 kernels only: their items are long (15-100 us) and the counter fetch hides under a 3-12 us epilogue; the 1x1 items
+        // (4-20 us, 2 us epilogue) measured 5-20 % slower with it (the fetch delays wave 0 into the next stage barrier)
+        if (dynamic && deal_base && KS == 3) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
     }
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
