@@ -51,6 +51,7 @@ _SIGS = {
     "ay_slice_accumulate_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ay_yolo_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "ay_yolo_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
+    "ay_conv1x1_cat_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P, _P, _P, _P]),
     "ay_resblock_supported": (_I, [_I]),
     "ay_resblock_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ay_match_detections": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _P, _P]),

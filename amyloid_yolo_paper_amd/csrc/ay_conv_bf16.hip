@@ -586,8 +586,9 @@ __device__ unsigned long long g_phase_ticks[8];
 // dynamic item dealing: 64 rotating sets of {8 per-XCD item counters, exit counter}; zero at load, reset by the last workgroup
 __device__ unsigned g_deal[64][16];
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
+    static_assert(!CAT || (KS == 1 && STRIDE == 1), "route + upsample folding exists for the 1x1 kernel");
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
     constexpr int NPIX = TH * TW;
@@ -673,6 +674,12 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     // ---- loader: piece i of this wave is global piece q = i*8 + wave ------------------------------------------
     // kind: pixel piece (kk, j) | filter piece (kk, j) | dummy.  Per lane: byte offset from the item's base, or -1.
     int src_off[PW];
+    // CAT (models.py:244-245 route of [upsampled x2 | direct] folded into this 1x1): stages below c1 channels read `src1`
+    // at half resolution (pixel (y>>1, x>>1)), the rest `src`; c1 is a multiple of the stage's NK*16 channels
+    int src_off1[CAT ? PW : 1];
+    const uint8_t* ld_src1 = nullptr;
+    const size_t in_plane1 = (size_t)(a.hin >> 1) * (a.win >> 1) * 32;
+    const int s1_stages = CAT ? a.c1 / (16 * NK) : 0;
     const uint8_t* ld_src = nullptr;
     const uint8_t* ld_w = nullptr;
     int ld_item = item, ld_s = 0, ld_par = 0;
@@ -683,22 +690,25 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         const int pt = it / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
-        ld_src = a.src + (size_t)b * (a.cin / 16) * in_plane;
+        ld_src = a.src + (size_t)b * ((a.cin - (CAT ? a.c1 : 0)) / 16) * in_plane;
+        if constexpr (CAT) ld_src1 = a.src1 + (size_t)b * (a.c1 / 16) * in_plane1;
         ld_w = a.w + (size_t)cg * BN * 16;
         // lanes 0..BN/4-1 fetch 4 scales each, lanes 32..32+BN/4-1 the shifts: LDS image [scale | pad to 128][shift]
         ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int q = i * 8 + wave;
-            int off = -1;
+            int off = -1, off1 = -1;
             if (q < NK * PX_PIECES) {
                 const int kk = q / PX_PIECES, j = q % PX_PIECES;
                 const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX]
                 const int h = u / IN_PIX, P = u % IN_PIX;
                 const int iy = y0 * STRIDE - PAD + P / IN_W;
                 const int ix = x0 * STRIDE - PAD + P % IN_W;
-                if (h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                if (h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
                     off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+                    off1 = (int)(kk * in_plane1) + ((iy >> 1) * (a.win >> 1) + (ix >> 1)) * 32 + h * 16;
+                }
             } else if (q < NPIECE) {
                 const int qq = q - NK * PX_PIECES;
                 const int u = qq * 64 + lane;          // unit inside the stage's filter image [kk][tap][half][BN]
@@ -706,17 +716,19 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 off = (th * CP + r) * 16;
             }
             src_off[i] = off;
+            if constexpr (CAT) src_off1[i] = off1;
         }
     };
     auto issue_piece = [&](int i, int buf) __attribute__((always_inline)) {  // DMA piece i of the loader's current stage into ring slot `buf`
-        const uint8_t* sp = ld_src + (size_t)ld_s * NK * in_plane;
+        const bool from1 = CAT && ld_s < s1_stages;  // wave-uniform
+        const uint8_t* sp = from1 ? ld_src1 + (size_t)ld_s * NK * in_plane1 : ld_src + (size_t)(ld_s - s1_stages) * NK * in_plane;
         const uint8_t* wp = ld_w + (size_t)ld_s * w_stage_stride;
         const int q = i * 8 + wave;  // wave-uniform
         const uint8_t* g;
         int dst;
         if (q < NK * PX_PIECES) {
             const int kk = q / PX_PIECES, j = q % PX_PIECES;
-            g = sp + src_off[i];
+            g = sp + (from1 ? src_off1[CAT ? i : 0] : src_off[i]);
             dst = buf * BUF_BYTES + kk * PIX_SLAB + j * 1024;
         } else if (q < NPIECE) {
             g = wp + src_off[i];
@@ -952,6 +964,8 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     static const int stagger = getenv("AY_STAGGER") ? atoi(getenv("AY_STAGGER")) : 0;
     a.stagger = stagger;
     a.deal = nullptr;
+    a.src1 = nullptr;
+    a.c1 = 0;
     if (V2 && conv_mode() >= 4) {
         static const int dynamic = getenv("AY_DYNAMIC") ? atoi(getenv("AY_DYNAMIC")) : 1;
         static unsigned* deal_base = nullptr;
@@ -1019,7 +1033,60 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     return AY_OK;
 }
 
+// 1x1 convolution over the route [nearest-x2-upsampled src1 | src2] (models.py:86-96,244-245) without materialising it
+static int launch_cat(const ay_conv_desc* d, const void* src1, int c1, const void* src2, const void* w, const float* scale,
+                      const float* shift, void* out, hipStream_t st) {
+    constexpr int BN = 128, TH = 8, TW = 32, NK = 4;
+    ConvArgs a;
+    a.src = (const uint8_t*)src2;
+    a.src1 = (const uint8_t*)src1;
+    a.c1 = c1;
+    a.w = (const uint8_t*)w;
+    a.scale = scale;
+    a.shift = shift;
+    a.residual = nullptr;
+    a.out = (uint8_t*)out;
+    a.batch = d->batch;
+    a.cin = d->cin;
+    a.cout_pad = d->cout_pad;
+    a.hin = d->hin;
+    a.win = d->win;
+    a.hout = d->hout;
+    a.wout = d->wout;
+    a.tiles_x = (d->wout + TW - 1) / TW;
+    a.tiles_y = (d->hout + TH - 1) / TH;
+    a.n_cgroups = d->cout_pad / BN;
+    a.leaky = d->leaky;
+    a.dbg = 0;
+    a.stagger = 0;
+    a.deal = nullptr;
+    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        set_error("conv grid out of range (%lld)", nblk);
+        return AY_ERR_ARG;
+    }
+    const int per_xcd = (int)((nblk + 7) / 8);
+    const int cu_slots = conv_num_cus() / 8;
+    dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
+    constexpr int NBUF = ring_depth<1, 1, BN, TH, TW, NK>();
+    hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, 2, 4, TH, TW, NK, NBUF, false, true>), pgrid, dim3(512), 0, st, a, (int)nblk);
+    AY_CHECK_LAUNCH("conv_bf16_ring_kernel<cat>");
+    return AY_OK;
+}
+
 }  // namespace ay
+
+extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                                       const float* scale, const float* shift, void* out, ay_stream_t stream) {
+    using namespace ay;
+    AY_CHECK_ARG(d && src1_halfres && src2 && w_packed && scale && shift && out, "ay_conv1x1_cat_fwd_bf16: null argument");
+    AY_CHECK_ARG(d->ksize == 1 && d->stride == 1 && !d->out_f32, "ay_conv1x1_cat_fwd_bf16: 1x1 stride-1 bf16 only");
+    AY_CHECK_ARG(c1 > 0 && c1 % 64 == 0 && d->cin > c1 && (d->cin - c1) % 64 == 0, "ay_conv1x1_cat_fwd_bf16: channel split %d + %d",
+                 c1, d->cin - c1);
+    AY_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->cout, "ay_conv1x1_cat_fwd_bf16: cout_pad %d (multiple of 128)", d->cout_pad);
+    AY_CHECK_ARG(d->hin % 2 == 0 && d->win % 2 == 0 && d->hout == d->hin && d->wout == d->win, "ay_conv1x1_cat_fwd_bf16: even sizes");
+    return launch_cat(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
+}
 
 extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
                                 const float* shift, const void* residual, void* out, ay_stream_t stream) {

@@ -26,6 +26,8 @@ struct ConvArgs {
     int dbg;  // timing experiments only (AY_DBG): 1 = no staging in the stage loop, 2 = no MFMA phase
     int stagger;  // ring kernel: start workgroup (slot & 3) after slot&3 x stagger x ~4 us, so that the CUs' epilogue
                   // (HBM) phases do not coincide
+    const uint8_t* src1;  // ring kernel, CAT variant: the first c1 input channels come from this tensor at half resolution
+    int c1;               // (nearest x2 upsample folded into the loader); `src` then holds channels c1..cin-1
     unsigned* deal;  // ring kernel: per-launch work counters (8 per-XCD item counters + 1 exit counter), nullptr = static dealing
 };
 

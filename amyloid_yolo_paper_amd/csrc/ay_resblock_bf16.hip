@@ -372,6 +372,8 @@ extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const 
     a.dbg = 0;
     a.stagger = 0;
     a.deal = nullptr;
+    a.src1 = nullptr;
+    a.c1 = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;
     AY_CHECK_ARG(n_items > 0 && n_items < 0x7fffffffLL, "ay_resblock_fwd_bf16: grid");
     return channels == 128 ? launch_resblock<64, 8, 2, 3>(s, (int)n_items, S(stream)) : launch_resblock<32, 16, 1, 4>(s, (int)n_items, S(stream));

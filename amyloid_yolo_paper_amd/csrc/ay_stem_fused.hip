@@ -308,6 +308,8 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     a.dbg = 0;
     a.stagger = 0;
     a.deal = nullptr;
+    a.src1 = nullptr;
+    a.c1 = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;
     AY_CHECK_ARG(n_items > 0 && n_items < 0x7fffffffLL, "ay_stem_s2_fused_fwd: grid");
     const int per_xcd = (int)((n_items + 7) / 8);

@@ -119,6 +119,7 @@ class Darknet(nn.Module):
         self.keep_layer_outputs = False
         self.layer_outputs = None
         self.stem_mode = "fused_bf16"   # "fp32": separate fp32 stem kernel (layer 0 output materialised)
+        self.fold_routes = True         # route [upsampled | direct] -> 1x1 conv without materialising the concatenation
         self.fuse_blocks = True         # fused residual-block kernel for the C=64/128 blocks (False: two conv launches)
         self.box_loss = "mse"           # "giou": 1 - GIoU replaces the four squared-error box terms (new feature; the
                                         # reference has only the MSE form, models.py:183-186)
@@ -445,6 +446,13 @@ class Darknet(nn.Module):
                         o = buf(tgt)
                         check(L.ay_stem_conv_fwd(ptr(x), ptr(p["w"]), ptr(p["scale"]), ptr(p["shift"]), ptr(o), B, S, S,
                                                  int(e["leaky"]), st), "ay_stem_conv_fwd")
+                    elif e["src"] >= 0 and val[e["src"]][0] == "catup":
+                        ra, rb = val[e["src"]][1]
+                        s1 = resolve(val[ra][1])      # half-resolution source of the lazy upsample
+                        s2 = resolve(rb)
+                        o = buf(tgt)
+                        check(L.ay_conv1x1_cat_fwd_bf16(C.byref(d), ptr(s1), self._graph[ra]["channels"], ptr(s2), ptr(p["packed"]),
+                                                        ptr(p["scale"]), ptr(p["shift"]), ptr(o), st), "ay_conv1x1_cat_fwd_bf16")
                     else:
                         src = x if e["src"] < 0 else resolve(e["src"])
                         if e["src"] < 0:
@@ -480,7 +488,9 @@ class Darknet(nn.Module):
                 if len(srcs) == 1:
                     val[i] = val[srcs[0]] if val[srcs[0]][0] != "up" else ("t", resolve(srcs[0]))
                 elif len(srcs) == 2:
-                    if bf16:
+                    if bf16 and self._cat_foldable(i, val):
+                        val[i] = ("catup", srcs)  # [upsampled x2 | direct]: folded into the loader of the next 1x1 conv
+                    elif bf16:
                         a, b_ = srcs
                         up = val[a][0] == "up"
                         s1 = resolve(val[a][1]) if up else resolve(a)
@@ -507,6 +517,19 @@ class Darknet(nn.Module):
         if self.keep_layer_outputs:
             self.layer_outputs = {i: v[1] for i, v in val.items() if v[0] == "t"}
         return out
+
+    def _cat_foldable(self, i, val):
+        """route i = [lazily upsampled a | b] whose only consumer is the next layer, a 1x1 bf16 conv block the dual-source
+        kernel covers (channel split in multiples of 64, padded cout a multiple of 128, not fused into a shortcut)"""
+        if not self.fold_routes or self.keep_layer_outputs:
+            return False
+        a, b_ = self._graph[i]["srcs"]
+        if val[a][0] != "up" or val[b_][0] != "t" or self._users[i] != [i + 1] or i + 1 >= len(self._graph):
+            return False
+        e = self._graph[i + 1]
+        ca, cb = self._graph[a]["channels"], self._graph[b_]["channels"]
+        return (e["type"] == "convolutional" and e["k"] == 1 and e["stride"] == 1 and e["bn"] and not e["fuse_into_shortcut"]
+                and not e.get("fuse_block") and ca % 64 == 0 and cb % 64 == 0 and _pad_to(e["cout"], 32) % 128 == 0)
 
     def _f32_sources(self, src, x, val, resolve):
         """(src1, cin1, up1, src2) for the fp32 kernel, folding route/upsample chains."""

@@ -80,6 +80,12 @@ int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const flo
 int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
                      const float* shift, const void* residual, void* out, ay_stream_t stream);
 
+/* The same 1x1 convolution over a route that is never materialised (models.py:86-96,244-245): input channels
+ * [0, c1) come from src1_halfres ([B][c1/16][H/2][W/2][16], nearest x2 upsample folded into the loader), channels
+ * [c1, cin) from src2 ([B][(cin-c1)/16][H][W][16]); c1 and cin-c1 multiples of 64, cout_pad a multiple of 128. */
+int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                            const float* scale, const float* shift, void* out, ay_stream_t stream);
+
 /* Fused Darknet-53 residual block (models.py:26-45 twice + the shortcut at :246-248):
  * out = leaky(bn2(conv3x3(leaky(bn1(conv1x1(x)))))) + x, channels C -> C/2 -> C, in one kernel: the C/2-channel
  * intermediate stays in LDS.  x/out blocked bf16 [B][C/16][H][W][16] (out != x); w1_packed = ay_pack_conv_weights_bf16 of

@@ -511,3 +511,42 @@ def test_forward_is_deterministic_under_dynamic_dealing(tmp_cfg_dir, dev):
         out = m(x)
         assert torch.equal(out, ref), rep
     assert bool(torch.isfinite(ref).all())
+
+
+@pytest.mark.parametrize("case", [(256, 512, 256, 16), (128, 256, 128, 26), (64, 64, 128, 8)], ids=str)
+def test_conv1x1_cat_kernel(dev, case):
+    """ay_conv1x1_cat_fwd_bf16 (route [upsampled x2 | direct] folded into the 1x1 loader) is BIT-identical to
+    ay_concat_upsample_bf16 followed by ay_conv_fwd_bf16 (same operands, same K order)."""
+    c1, c2, cout, H = case
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    B = 2
+    g = torch.Generator().manual_seed(c1 + c2 + H)
+    a_half = _bf16r(torch.randn(B, c1, H // 2, H // 2, generator=g))
+    b_full = _bf16r(torch.randn(B, c2, H, H, generator=g))
+    w = torch.randn(cout, c1 + c2, 1, 1, generator=g) * (1.0 / np.sqrt(c1 + c2))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ad, bd, wd, sc, sh = a_half.to(dev), b_full.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    ab = torch.empty(B, c1 // 16, H // 2, H // 2, 16, device=dev, dtype=torch.bfloat16)
+    bb = torch.empty(B, c2 // 16, H, H, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(ad), ptr(ab), B, c1, H // 2, H // 2, st))
+    check(L.ay_nchw_f32_to_blocked_bf16(ptr(bd), ptr(bb), B, c2, H, H, st))
+    packed = torch.empty(L.ay_packed_weight_bytes(cout, c1 + c2, 1), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_conv_weights_bf16(ptr(wd), ptr(packed), cout, cout, c1 + c2, 1, st))
+    cat = torch.empty(B, (c1 + c2) // 16, H, H, 16, device=dev, dtype=torch.bfloat16)
+    check(L.ay_concat_upsample_bf16(ptr(ab), c1, 1, ptr(bb), c2, ptr(cat), B, H, H, st))
+    d = ConvDesc(B, c1 + c2, cout, H, H, H, H, 1, 1, 1, 0, cout)
+    o_ref = torch.full((B, cout // 16, H, H, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    o_cat = torch.full_like(o_ref, float("nan"))
+    check(L.ay_conv_fwd_bf16(C.byref(d), ptr(cat), ptr(packed), ptr(sc), ptr(sh), None, ptr(o_ref), st))
+    check(L.ay_conv1x1_cat_fwd_bf16(C.byref(d), ptr(ab), c1, ptr(bb), ptr(packed), ptr(sc), ptr(sh), ptr(o_cat), st))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o_cat.float()).all())
+    assert torch.equal(o_cat.view(torch.int16), o_ref.view(torch.int16))
+    # and against torch: upsample + cat + conv on the CPU
+    ref = F.conv2d(torch.cat([F.interpolate(a_half, scale_factor=2, mode="nearest"), b_full], 1), _bf16r(w))
+    ref = _bf16r(F.leaky_relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1))
+    got = torch.empty(B, cout, H, H, device=dev)
+    check(L.ay_blocked_bf16_to_nchw_f32(ptr(o_cat), ptr(got), B, cout, H, H, st))
+    err = (got.cpu() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-3).all()), float(err.max())
