@@ -81,8 +81,8 @@ class FlatGradReducer:
 
     def all_reduce(self, average=True):
         """sum over ranks (bucketed, async, reverse order), then 1/world; returns the number of bytes exchanged per rank"""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return 0
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not os.environ.get("AY_FORCE_DIST")):
+            return 0  # (AY_FORCE_DIST: run the collectives with one rank too -- rehearsal of the N>1 path on a 1-GPU box)
         assert self.views_intact(), "parameter .grad no longer aliases the flat buffer (zero_grad(set_to_none=True)?)"
         world = dist.get_world_size(self.group)
         handles = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -96,7 +96,7 @@ class FlatGradReducer:
 
 def broadcast_parameters(module, src=0, group=None):
     """make every replica start from rank `src`'s weights and BN statistics"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not os.environ.get("AY_FORCE_DIST")):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)

@@ -17,6 +17,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+USE_DIST = False
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
@@ -66,8 +67,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # AY_FORCE_DIST=1 walks the process-group code path with a single rank too (rehearsal of the N>1 launch on a 1-GPU box)
+    global USE_DIST
+    USE_DIST = world > 1 or bool(os.environ.get("AY_FORCE_DIST"))
+    if USE_DIST:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from amyloid_yolo_paper_amd import _lib, build as aybuild, cfg_gen, parse_config, synth
@@ -80,7 +87,7 @@ def main():
     if not os.path.exists(_lib.LIB_PATH):
         if rank == 0:
             aybuild.build_library(verbose=False)
-        if world > 1:
+        if USE_DIST:
             dist.barrier()
 
     cfg = cfg_gen.write_cfg(a.classes)
@@ -135,7 +142,7 @@ def main():
     for _ in range(a.warmup):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
     model.profile_layers = None if a.no_layer_events else set(fam)
     model.profile_events = []
@@ -144,11 +151,11 @@ def main():
     for _ in range(a.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if USE_DIST:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,7 +199,7 @@ def main():
         if not a.no_cpu_baseline and a.gpus == 1:
             result["cpu_baseline"] = cpu_baseline(a, cfg, params)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -231,17 +238,17 @@ def bench_train(a, rank, local_rank, world, dev):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses.append(step())
     torch.cuda.synchronize()
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if USE_DIST:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -259,7 +266,7 @@ def bench_train(a, rank, local_rank, world, dev):
     }
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
         dist.destroy_process_group()
 
