@@ -603,12 +603,14 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     constexpr int W_SLAB = W_PIECES * 1024;
     constexpr int W_BASE = NK * PIX_SLAB;
     constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
-    constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);     // + one piece that carries this item's scale/shift
-    constexpr int PW = (NPIECE + 1 + 7) / 8;                // pieces per wave per stage (dummy-padded)
+    constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);     // + the piece(s) that carry this item's scale/shift
+    constexpr int SSP = BN > 128 ? 2 : 1;                   // BN <= 128: one piece [scale | shift]; 256: a scale piece, a shift piece
+    constexpr int SSR = SSP * 1024;                         // bytes of one scale/shift region
+    constexpr int PW = (NPIECE + SSP + 7) / 8;              // pieces per wave per stage (dummy-padded)
     constexpr int DUMMY_BASE = NBUF * BUF_BYTES;
     constexpr int SS_BASE = DUMMY_BASE + 1024;              // 4 x 1 KiB [scale 128][shift 128], by item index & 3 (the loader
                                                             // runs at most NBUF-1 <= 2 items ahead of the epilogue)
-    constexpr int MBOX_BASE = NBUF * BUF_BYTES + 5 * 1024;  // 8 ints: item ids by sequence number & 7
+    constexpr int MBOX_BASE = NBUF * BUF_BYTES + 1024 + 4 * SSR;  // 8 ints: item ids by sequence number & 7
     constexpr int LDS_BYTES = MBOX_BASE + 64;
     static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
     static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
@@ -694,7 +696,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         if constexpr (CAT) ld_src1 = a.src1 + (size_t)b * (a.c1 / 16) * in_plane1;
         ld_w = a.w + (size_t)cg * BN * 16;
         // lanes 0..BN/4-1 fetch 4 scales each, lanes 32..32+BN/4-1 the shifts: LDS image [scale | pad to 128][shift]
-        ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
+        if constexpr (SSP == 1)
+            ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
+        else  // 256 channels: lane l carries scales (piece NPIECE) / shifts (piece NPIECE + 1) 4l..4l+3
+            ld_ss = a.scale + (size_t)cg * BN + lane * 4;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int q = i * 8 + wave;
@@ -735,12 +740,15 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
         } else if (q == NPIECE) {
             g = reinterpret_cast<const uint8_t*>(ld_ss);
-            dst = SS_BASE + ld_par * 1024;
+            dst = SS_BASE + ld_par * SSR;
+        } else if (SSP == 2 && q == NPIECE + 1) {
+            g = reinterpret_cast<const uint8_t*>(ld_ss + (a.shift - a.scale));  // same lane offset in the shift array
+            dst = SS_BASE + ld_par * SSR + 1024;
         } else {
             g = zero_page;
             dst = DUMMY_BASE;
         }
-        if (q == NPIECE ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
+        if (q >= NPIECE && q < NPIECE + SSP ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
         dma16(g, lds_base + __builtin_amdgcn_readfirstlane(dst));
     };
     auto advance_loader = [&]() __attribute__((always_inline)) {
@@ -886,7 +894,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         int fetched = last;
         if (tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
         conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
-                                                                       reinterpret_cast<const float*>(lds + SS_BASE + par * 1024));
+                                                                       reinterpret_cast<const float*>(lds + SS_BASE + par * SSR));
         if (tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -916,7 +924,7 @@ template <int KS, int STRIDE, int BN, int TH, int TW, int NK>
 constexpr int ring_depth() {
     constexpr int in_pix = ((TH - 1) * STRIDE + KS) * ((TW - 1) * STRIDE + KS);
     constexpr int buf = NK * (((2 * in_pix + 63) / 64) * 1024 + KS * KS * 2 * BN * 16);
-    return (3 * buf + 5 * 1024 <= 160 * 1024) ? 3 : 2;
+    return (3 * buf + 1024 + 4 * (BN > 128 ? 2048 : 1024) + 64 <= 160 * 1024) ? 3 : 2;
 }
 
 // AY_CONV_MODE: 1 = V1 (4 waves, register staging), 2 = V2 (8 waves, DMA filters), 3 = V3 persistent,
@@ -1033,10 +1041,13 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     return AY_OK;
 }
 
-// 1x1 convolution over the route [nearest-x2-upsampled src1 | src2] (models.py:86-96,244-245) without materialising it
-static int launch_cat(const ay_conv_desc* d, const void* src1, int c1, const void* src2, const void* w, const float* scale,
-                      const float* shift, void* out, hipStream_t st) {
-    constexpr int BN = 128, TH = 8, TW = 32, NK = 4;
+// 1x1 ring kernel launched directly (no residual): CAT = over the route [nearest-x2-upsampled src1 | src2]
+// (models.py:86-96,244-245) without materialising it; BN = 256 = all of a 256-channel group per workgroup (twice the MFMAs per
+// stage barrier of the 128-channel tile, input pixels read once per 256 instead of per 128 output channels)
+template <int BN, int WM, int WN, bool CAT>
+static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const void* src2, const void* w, const float* scale,
+                          const float* shift, void* out, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NK = 4;
     ConvArgs a;
     a.src = (const uint8_t*)src2;
     a.src1 = (const uint8_t*)src1;
@@ -1069,8 +1080,8 @@ static int launch_cat(const ay_conv_desc* d, const void* src1, int c1, const voi
     const int cu_slots = conv_num_cus() / 8;
     dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     constexpr int NBUF = ring_depth<1, 1, BN, TH, TW, NK>();
-    hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, 2, 4, TH, TW, NK, NBUF, false, true>), pgrid, dim3(512), 0, st, a, (int)nblk);
-    AY_CHECK_LAUNCH("conv_bf16_ring_kernel<cat>");
+    hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
+    AY_CHECK_LAUNCH("conv_bf16_ring_kernel<1x1>");
     return AY_OK;
 }
 
@@ -1085,7 +1096,7 @@ extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_h
                  c1, d->cin - c1);
     AY_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->cout, "ay_conv1x1_cat_fwd_bf16: cout_pad %d (multiple of 128)", d->cout_pad);
     AY_CHECK_ARG(d->hin % 2 == 0 && d->win % 2 == 0 && d->hout == d->hin && d->wout == d->win, "ay_conv1x1_cat_fwd_bf16: even sizes");
-    return launch_cat(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
+    return launch_ring1x1<128, 2, 4, true>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
 }
 
 extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
@@ -1130,6 +1141,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
         }
         const int v1 = conv_mode() == 1;
+        static const int bn256 = getenv("AY_BN256") ? atoi(getenv("AY_BN256")) : 1;
+        if (cp % 256 == 0 && !residual && conv_mode() >= 4 && bn256)
+            return launch_ring1x1<256, 4, 2, false>(d, nullptr, 0, src, w_packed, scale, shift, out, st);
         if (cp % 128 == 0 && !v1) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0 && !v1) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<1, 1, 128, 2, 2, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);

@@ -71,7 +71,7 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 }
 
 // RES_INLINE: the residual is loaded here, one 32-pixel block ahead of its use (large wave tiles cannot hold all of it).
-// SS_MODE 1|2 (ss_lds != nullptr; 0 = from global memory): per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift],
+// SS_MODE 1|2 (ss_lds != nullptr; 0 = from global memory): per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift] (shift at float offset max(BN, 128)),
 // so the epilogue issues no vector-memory loads that would have to wait behind its own stores.
 template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
@@ -80,6 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const size_t out_plane_px = (size_t)a.hout * a.wout;
     const int cbase = cg * BN + wm * MT * 32;
     const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
+    constexpr int SHO = BN > 128 ? BN : 128;  // float offset of the shifts in the LDS scale/shift image
 
     // residual of (n, m) 32x32 blocks, loaded RD blocks ahead of their use: a load issued only one block (~150 cycles)
     // ahead exposes nearly the whole memory latency on every block; the MFMA fragment registers are dead here, so the
@@ -127,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                         typedef __attribute__((address_space(3))) const f32x4 lds_f4;
                         lds_f4* sl = (lds_f4*)(__attribute__((address_space(3))) const float*)ss_lds;
                         const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;  // multiple of 4 floats
-                        const f32x4 a0 = sl[l0 >> 2], b0 = sl[(128 + l0) >> 2], a1 = sl[(l0 + 8) >> 2], b1 = sl[(128 + l0 + 8) >> 2];
+                        const f32x4 a0 = sl[l0 >> 2], b0 = sl[(SHO + l0) >> 2], a1 = sl[(l0 + 8) >> 2], b1 = sl[(SHO + l0 + 8) >> 2];
                         s0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
                         t0 = make_float4(b0[0], b0[1], b0[2], b0[3]);
                         s1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
@@ -136,9 +137,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                                           // ring kernels; the code shape matters there: they sit at 256 VGPRs without a spill)
                         const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;
                         s0 = *reinterpret_cast<const float4*>(ss_lds + l0);
-                        t0 = *reinterpret_cast<const float4*>(ss_lds + 128 + l0);
+                        t0 = *reinterpret_cast<const float4*>(ss_lds + SHO + l0);
                         s1 = *reinterpret_cast<const float4*>(ss_lds + l0 + 8);
-                        t1 = *reinterpret_cast<const float4*>(ss_lds + 128 + l0 + 8);
+                        t1 = *reinterpret_cast<const float4*>(ss_lds + SHO + l0 + 8);
                     } else {
                         s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
                         t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);

@@ -140,6 +140,9 @@ CONV_CASES = [
     (256, 255, 1, 1, 8, False, False, True),    # COCO-sized head, 255->256
     (48, 96, 1, 1, 16, True, False, False),     # cin not a multiple of 64 (NK=1 path)
     (512, 1024, 3, 1, 8, True, True, False),    # deep K loop
+    (512, 256, 1, 1, 20, True, False, False),   # 1x1 with the 256-channel tile (BN=256), ragged
+    (1024, 512, 1, 1, 13, True, False, False),  # 1x1 BN=256, two channel groups, 13x13
+    (256, 256, 1, 1, 32, False, False, False),  # 1x1 BN=256, linear
 ]
 
 
