@@ -641,7 +641,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     // epilogue of item c (the atomic's latency hides under it) and posts it at its end; the stage barriers publish it long
     // before the loader (at most 2 item boundaries ahead) or the MFMA side need it.  Without counters the same mailbox
     // carries the static ids.
-    const bool dyn = a.deal != nullptr;
+    // MAILBOX = 3x3 kernels (their items are long); the 1x1 kernels keep plain strided dealing with no mailbox traffic at
+    // all: their 8-20 us items lost 5-20 % to it
+    constexpr bool MAILBOX = (KS == 3);
+    const bool dyn = MAILBOX && a.deal != nullptr;
     auto leave = [&]() __attribute__((always_inline)) {
         if (dyn && tid == 0) {
             const unsigned d = atomicAdd(a.deal + 8, 1u);
@@ -661,9 +664,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         if (prev >= last) return last;
         return dyn ? first + D * slots + (int)atomicAdd(a.deal + xcd, 1u) : prev + slots;
     };
-    if (tid < D) mbox[tid] = min(item + tid * slots, last);  // the first D items of a workgroup are static (no atomics, no
+    if (MAILBOX && tid < D) mbox[tid] = min(item + tid * slots, last);  // the first D items of a workgroup are static (no atomics, no
                                                              // wait in the prologue); id[c+D] is posted by the epilogue of item c
-    __syncthreads();  // ids 0..D-1 posted (a single-stage item makes the loader ask for id 1 already in the prologue below)
+    if constexpr (MAILBOX) __syncthreads();  // ids 0..D-1 posted (a single-stage item makes the loader ask for id 1 already in the prologue below)
     int seq_l = 0, seq_c = 0;  // sequence numbers of the loader's / the MFMA side's current item
 
     const size_t in_plane = (size_t)a.hin * a.win * 32;
@@ -756,7 +759,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             ld_s = 0;
             ld_par = (ld_par + 1) & 3;
             ++seq_l;
-            ld_item = __builtin_amdgcn_readfirstlane(mbox[seq_l & 7]);
+            if constexpr (MAILBOX)
+                ld_item = __builtin_amdgcn_readfirstlane(mbox[seq_l & 7]);
+            else
+                ld_item += slots;
             if (ld_item < last)
                 setup_loader(ld_item);
             else
@@ -811,7 +817,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
-        const int next_item = __builtin_amdgcn_readfirstlane(mbox[(seq_c + 1) & 7]);
+        const int next_item = MAILBOX ? __builtin_amdgcn_readfirstlane(mbox[(seq_c + 1) & 7]) : item + slots;
         const bool has_next = next_item < last;
 
         f32x16 acc[MT][NT];
@@ -892,10 +898,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             tk0 = t;
         }
         int fetched = last;
-        if (tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
+        if (MAILBOX && tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
         conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                        reinterpret_cast<const float*>(lds + SS_BASE + par * SSR));
-        if (tid == 0) {
+        if (MAILBOX && tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
