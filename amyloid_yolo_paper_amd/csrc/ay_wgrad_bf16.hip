@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     const int cob = blockIdx.x, cib = blockIdx.y;
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_wgrad_zero_page);
+    const unsigned lds_base = lds_addr_of(lds);
 
     // segments of this workgroup: blockIdx.z, + gridDim.z, ...
     int seg = blockIdx.z;
@@ -95,8 +96,9 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
                 }
                 dst = buf * BUF_BYTES + qn * 1024;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
+            // inline-asm DMA: with the builtin hipcc placed `s_waitcnt vmcnt(0)` between the issue of stage k+3 and the first LDS
+            // read of stage k (it cannot prove the ring slots distinct), draining the whole ring every K step
+            dma16(src, lds_base + __builtin_amdgcn_readfirstlane(dst));
         }
     };
 
