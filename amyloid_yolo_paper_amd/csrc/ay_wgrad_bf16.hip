@@ -11,6 +11,8 @@
 // dimension and the partial filters are added to dW with fp32 atomics (dW is zeroed first).
 // LDS slots are XOR-swizzled (slot = px ^ ((px>>3 & 1) << 2)), through the DMA source address, so that the two 4-row blocks
 // a 32-lane half reads land on different banks.
+#include <stdlib.h>
+
 #include "ay_common.h"
 
 namespace ay {
@@ -223,7 +225,8 @@ extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, 
     AY_CHECK_ARG(total > 0 && total < 0x7fffffffLL, "ay_conv_wgrad_bf16: too many segments");
     a.total_segs = (int)total;
     const int cob = (a.COP + 7) / 8, cib = (a.CIP + 3) / 4;
-    long long ks = (512 + (long long)cob * cib - 1) / ((long long)cob * cib);   // ~2 workgroups per CU overall ...
+    static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
+    long long ks = (wg_target + (long long)cob * cib - 1) / ((long long)cob * cib);   // ~1 workgroup per CU overall (each pays ~300 KB of fp32 atomics at its end: 512 measured 3 % slower per step) ...
     if (ks > total / 24) ks = total / 24;                                        // ... but >= 24 K steps each (pipeline fill, atomics)
     if (ks > total) ks = total;
     if (ks > 65535) ks = 65535;
