@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--max_det", type=int, default=2048)
     ap.add_argument("--unique_tiles", type=int, default=16, help="distinct synthetic tiles (repeated to fill the batch)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_tiles", type=int, default=4)
+    ap.add_argument("--cpu_tiles", type=int, default=16, help="tiles in the CPU-oracle sample (configs[0]: 16 tiles, ~12 s)")
     ap.add_argument("--serial_nms", action="store_true", help="run merge-NMS on the main stream (no overlap with the next batch)")
     ap.add_argument("--no_layer_events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--traffic_json", default=os.path.join(REPO, "profiles", "traffic.json"),
