@@ -553,3 +553,4 @@ def test_conv1x1_cat_kernel(dev, case):
     check(L.ay_blocked_bf16_to_nchw_f32(ptr(o_cat), ptr(got), B, cout, H, H, st))
     err = (got.cpu() - ref).abs()
     assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-3).all()), float(err.max())
+
