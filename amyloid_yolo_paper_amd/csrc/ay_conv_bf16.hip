@@ -658,7 +658,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         leave();
         return;
     }
-    volatile int* mbox = reinterpret_cast<volatile int*>(lds + MBOX_BASE);
+    // explicit LDS address space: through a generic pointer these volatile accesses become flat_load/flat_store, which count on
+    // vmcnt as well, and hipcc then waits vmcnt(0) -- draining the DMA ring -- at every mailbox access
+    typedef volatile __attribute__((address_space(3))) int lds_vint;
+    lds_vint* mbox = (lds_vint*)(__attribute__((address_space(3))) int*)(lds + MBOX_BASE);
     const int D = (a.cin / (16 * NK)) >= 2 ? 3 : 5;  // fetch-ahead distance in items
     auto fetch_id = [&](int prev) __attribute__((always_inline)) -> int {  // thread 0 only
         if (prev >= last) return last;

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             stage_end(issued, !(last_stage && !has_next));
             if (++cur == NBUF) cur = 0;
         }
-        conv_epilogue<BN2, MT, NT, TW, false, true, true, 1>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN2, MT, NT, TW, false, true, true, 2>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
                                                             reinterpret_cast<const float*>(lds + OFF_SS2));
         if (!has_next) break;
         item = next_item;
