@@ -641,9 +641,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     // epilogue of item c (the atomic's latency hides under it) and posts it at its end; the stage barriers publish it long
     // before the loader (at most 2 item boundaries ahead) or the MFMA side need it.  Without counters the same mailbox
     // carries the static ids.
-    // MAILBOX = 3x3 kernels (their items are long); the 1x1 kernels keep plain strided dealing with no mailbox traffic at
-    // all: their 8-20 us items lost 5-20 % to it
-    constexpr bool MAILBOX = (KS == 3);
+    constexpr bool MAILBOX = true;  // (false: plain strided dealing without any mailbox traffic)
     const bool dyn = MAILBOX && a.deal != nullptr;
     auto leave = [&]() __attribute__((always_inline)) {
         if (dyn && tid == 0) {
@@ -991,9 +989,10 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             void* p = nullptr;
             if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_deal)) == hipSuccess) deal_base = (unsigned*)p;
         }
-        // 3x3 kernels only: their items are long (15-100 us) and the counter fetch hides under a 3-12 us epilogue; the 1x1 items
-        // (4-20 us, 2 us epilogue) measured 5-20 % slower with it (the fetch delays wave 0 into the next stage barrier)
-        if (dynamic && deal_base && KS == 3) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
+        // (the 1x1 kernels once measured 5-20 % slower with dynamic dealing: that was the flat-addressed mailbox draining the DMA
+        // ring, not the counter fetch; with the LDS-typed mailbox they gain slightly, AY_DYN1=0 turns it off for them)
+        static const int dyn1 = getenv("AY_DYN1") ? atoi(getenv("AY_DYN1")) : 1;
+        if (dynamic && deal_base && (KS == 3 || dyn1)) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
     }
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
