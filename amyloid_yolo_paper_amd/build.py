@@ -11,6 +11,7 @@ SOURCES = ["ay_layout.hip", "ay_conv_bf16.hip", "ay_conv_f32.hip", "ay_yolo.hip"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 if os.environ.get("AY_PHASE_CLOCK"):  # instrumented build: in-kernel phase clock of the ring convolution (AY_DBG=8 at run time)
     FLAGS.append("-DAY_PHASE_CLOCK")
+FLAGS += os.environ.get("AY_CXXFLAGS", "").split()  # experiment builds (e.g. -DAY_BUF_STORE=0)
 
 
 def _hipcc():

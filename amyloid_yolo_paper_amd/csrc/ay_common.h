@@ -30,6 +30,7 @@ void set_error(const char* fmt, ...);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // round-to-nearest-even f32 -> bf16 bits (plain cast: keeps NaN a NaN, v_cvt_pk_bf16_f32 at -O3)
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -41,6 +42,21 @@ __device__ __forceinline__ float bf2f(uint16_t u) {
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two floats -> one dword of bf16 (round to nearest even) in a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack2bf2(f32x2 v) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// one dword of bf16 -> two floats
+__device__ __forceinline__ f32x2 bf2f2(uint32_t u) {
+    return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+// LeakyReLU on two values: max(x, slope * x) equals x > 0 ? x : slope * x for 0 < slope <= 1 (slope 1: identity)
+__device__ __forceinline__ f32x2 leaky2(f32x2 x, float slope) {
+    const f32x2 y = x * slope;
+    return f32x2{__builtin_fmaxf(x[0], y[0]), __builtin_fmaxf(x[1], y[1])};
 }
 
 // 16-byte LDS-DMA (global_load_lds_dwordx4): lane l copies 16 B from its own `gsrc` to LDS byte address `lds_addr + 16*l`

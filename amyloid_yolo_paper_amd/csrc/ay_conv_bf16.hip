@@ -1119,6 +1119,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     AY_CHECK_ARG(d->hout == (d->hin + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (d->win + 2 * pad - d->ksize) / d->stride + 1,
                  "ay_conv_fwd_bf16: output size mismatch");
     AY_CHECK_ARG(!(d->out_f32 && residual), "ay_conv_fwd_bf16: f32 output has no residual form");
+    AY_CHECK_ARG((long long)d->hout * d->wout * 2 * d->cout_pad < (1ll << 31),
+                 "ay_conv_fwd_bf16: one image's output (%dx%dx%d) exceeds the 2 GiB a store descriptor addresses", d->hout, d->wout,
+                 d->cout_pad);
     hipStream_t st = S(stream);
     const int cp = d->cout_pad;
     if (d->ksize == 3 && d->stride == 1) {

@@ -70,9 +70,20 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
     }
 }
 
-// RES_INLINE: the residual is loaded here, one 32-pixel block ahead of its use (large wave tiles cannot hold all of it).
-// SS_MODE 1|2 (ss_lds != nullptr; 0 = from global memory): per-channel scale/shift of this workgroup's BN channels staged in LDS as [scale BN | pad to 128][shift] (shift at float offset max(BN, 128)),
-// so the epilogue issues no vector-memory loads that would have to wait behind its own stores.
+// RES_INLINE: the residual is loaded here, RD 32-pixel blocks ahead of its use (large wave tiles cannot hold all of it).
+// SS_MODE 1|2 (ss_lds != nullptr; 0 = from global memory): per-channel scale/shift of this workgroup's BN channels staged in
+// LDS as [scale BN | pad to 128][shift] (shift at float offset max(BN, 128)), so the epilogue issues no vector-memory loads
+// that would have to wait behind its own stores.
+// Deferred stores (residual loaded here): see below; they go out as unconditional buffer stores -- out-of-image lanes carry an
+// offset past num_records and the hardware drops them -- so that the compiler can count them (a store under `if (ok)` sits in
+// its own basic block and forces conservative waits).  The plane offset rides in the VECTOR offset: with it in the scalar-offset
+// field hipcc (following the ISA manual) puts no wait state between a 128-bit store and a VALU write of its data registers, and
+// gfx950 then stored the overwritten first dword for the last lanes of each row of 16 (seen in the parity tests).
+//
+// Arithmetic: packed fp32 (v_pk_mul_f32 / v_pk_add_f32 carry two values per issue slot), LeakyReLU as max(x, slope * x) with
+// slope 1 for linear layers, one v_cvt_pk_bf16_f32 per two outputs.  The epilogue is VALU-bound -- with scalar ops, compare +
+// select and one convert per value it cost ~85 VALU instructions per 8 outputs, 4-5 us per 16x32 item with no MFMA running.
+// The IEEE operations and their order are unchanged (no contraction), so are the results, bit for bit.
 template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
                                               int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr) {
@@ -81,21 +92,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const int cbase = cg * BN + wm * MT * 32;
     const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
     constexpr int SHO = BN > 128 ? BN : 128;  // float offset of the shifts in the LDS scale/shift image
+    const float slope = a.leaky ? 0.1f : 1.0f;
+    // buffer descriptor over image b's output; offsets >= num_records are dropped, so the out-of-image sentinel 0x80000000
+    // (+ a plane offset) needs an image below 2 GiB: host check
+    const unsigned plane_bytes = (unsigned)out_plane_px * 32u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + (size_t)__builtin_amdgcn_readfirstlane(b) * (CP / 16) * out_plane_px * 32, 0, (int)(plane_bytes * (unsigned)(CP / 16)),
+        0x00020000);
 
-    // residual of (n, m) 32x32 blocks, loaded RD blocks ahead of their use: a load issued only one block (~150 cycles)
-    // ahead exposes nearly the whole memory latency on every block; the MFMA fragment registers are dead here, so the
-    // deeper ring costs no extra registers
-    constexpr int RD = (MT * NT >= 4) ? 2 : MT * NT;
-    uint4 rres[RD][2];
+    // residual loaded here (RES_INLINE), RD blocks ahead of its use: vmcnt retires in order, STORES INCLUDED, so a residual load
+    // issued behind an output store cannot be waited for before that store has completed.  No store is therefore issued until
+    // the last residual load has been consumed: the packed bf16 outputs stay in registers (8 per 32x32 block, in the place of
+    // the block's 16 accumulators) and go out together at the end (-1.2 % on the 16x32 residual kernel).  A look-ahead that
+    // grows with the registers freed this way spilled (2 blocks more per finished block: 15 VGPRs; 256 is the budget), and
+    // warming L2 with one 4-byte LDS-DMA per residual line a stage ahead made the kernel 3 % SLOWER: the epilogue phase is
+    // bound by the HBM burst of residual + output of all CUs, not by the latency of a single load.
+    constexpr int NB = MT * NT;
+    constexpr int RD = (NB >= 4) ? 2 : NB;
+    constexpr bool DEFER = HAS_RES && RES_INLINE && !OUT_F32;
+    uint4 rres[NB][2];
+    u32x4 outv[DEFER ? NB : 1][2];
+    // residual through a buffer descriptor as well: a 32-bit pixel offset per lane + the plane in the scalar offset (no 64-bit
+    // address arithmetic in vector registers; this epilogue runs at the register limit)
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.residual) + (size_t)__builtin_amdgcn_readfirstlane(b) * (CP / 16) * out_plane_px * 32, 0,
+        (int)(plane_bytes * (unsigned)(CP / 16)), 0x00020000);
     auto load_res = [&](int t, uint4 (&r)[2]) __attribute__((always_inline)) {
         const int n = t / MT, m = t % MT;
         const int p = (wn * NT + n) * 32 + c;
         const int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1);  // clamped: see residual_prefetch
-        const size_t pix = (size_t)oy * a.wout + ox;
+        const unsigned pix_off = ((unsigned)oy * a.wout + ox) * 32u + hh * 16u;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-            const size_t plane = (size_t)b * (CP / 16) + ((cbase + m * 32 + qp * 16) >> 4);
-            r[qp] = *reinterpret_cast<const uint4*>(a.residual + (plane * out_plane_px + pix) * 32 + hh * 16);
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, pix_off, so, 0);
+            r[qp] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
     if constexpr (HAS_RES && RES_INLINE) {
@@ -106,100 +137,97 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
         const int oy = y0 + p / TW, ox = x0 + p % TW;
-        const bool ok = (oy < a.hout) && (ox < a.wout);
+        const bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            uint4 rcur[2];
-            if constexpr (HAS_RES && RES_INLINE) {
-                rcur[0] = rres[(n * MT + m) % RD][0];
-                rcur[1] = rres[(n * MT + m) % RD][1];
-                if (n * MT + m + RD < NT * MT) load_res(n * MT + m + RD, rres[(n * MT + m) % RD]);
-            }
+            const int t = n * MT + m;
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
                 const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
-                float v[4], w[4];
+                f32x2 v01, v23, w01, w23;                  // quad 2qp, quad 2qp+1
                 {
-                    float4 s0, t0, s1, t1;
+                    f32x4 s0, t0, s1, t1;
                     if constexpr (SS_MODE == 2) {
                         // explicit LDS address space: through a generic pointer the compiler may emit flat loads, which
                         // count on vmcnt too and make it wait for every LDS-DMA in flight (seen in the fused stem)
                         typedef __attribute__((address_space(3))) const f32x4 lds_f4;
                         lds_f4* sl = (lds_f4*)(__attribute__((address_space(3))) const float*)ss_lds;
                         const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;  // multiple of 4 floats
-                        const f32x4 a0 = sl[l0 >> 2], b0 = sl[(SHO + l0) >> 2], a1 = sl[(l0 + 8) >> 2], b1 = sl[(SHO + l0 + 8) >> 2];
-                        s0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                        t0 = make_float4(b0[0], b0[1], b0[2], b0[3]);
-                        s1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                        t1 = make_float4(b1[0], b1[1], b1[2], b1[3]);
+                        s0 = sl[l0 >> 2], t0 = sl[(SHO + l0) >> 2], s1 = sl[(l0 + 8) >> 2], t1 = sl[(SHO + l0 + 8) >> 2];
                     } else if (ss_lds) {  // SS_MODE 1: LDS through the generic pointer, run-time test kept (resolves to ds_read in the
                                           // ring kernels; the code shape matters there: they sit at 256 VGPRs without a spill)
                         const int l0 = lbase + m * 32 + qp * 16 + 4 * hh;
-                        s0 = *reinterpret_cast<const float4*>(ss_lds + l0);
-                        t0 = *reinterpret_cast<const float4*>(ss_lds + SHO + l0);
-                        s1 = *reinterpret_cast<const float4*>(ss_lds + l0 + 8);
-                        t1 = *reinterpret_cast<const float4*>(ss_lds + SHO + l0 + 8);
+                        s0 = *reinterpret_cast<const f32x4*>(ss_lds + l0);
+                        t0 = *reinterpret_cast<const f32x4*>(ss_lds + SHO + l0);
+                        s1 = *reinterpret_cast<const f32x4*>(ss_lds + l0 + 8);
+                        t1 = *reinterpret_cast<const f32x4*>(ss_lds + SHO + l0 + 8);
                     } else {
-                        s0 = *reinterpret_cast<const float4*>(a.scale + ch0 + 4 * hh);
-                        t0 = *reinterpret_cast<const float4*>(a.shift + ch0 + 4 * hh);
-                        s1 = *reinterpret_cast<const float4*>(a.scale + ch0 + 8 + 4 * hh);
-                        t1 = *reinterpret_cast<const float4*>(a.shift + ch0 + 8 + 4 * hh);
+                        s0 = *reinterpret_cast<const f32x4*>(a.scale + ch0 + 4 * hh);
+                        t0 = *reinterpret_cast<const f32x4*>(a.shift + ch0 + 4 * hh);
+                        s1 = *reinterpret_cast<const f32x4*>(a.scale + ch0 + 8 + 4 * hh);
+                        t1 = *reinterpret_cast<const f32x4*>(a.shift + ch0 + 8 + 4 * hh);
                     }
-                    const float ss0[4] = {s0.x, s0.y, s0.z, s0.w}, tt0[4] = {t0.x, t0.y, t0.z, t0.w};
-                    const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, tt1[4] = {t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x0v = acc[m][n][(2 * qp) * 4 + j] * ss0[j] + tt0[j];
-                        float x1v = acc[m][n][(2 * qp + 1) * 4 + j] * ss1[j] + tt1[j];
-                        if (a.leaky) {
-                            x0v = x0v > 0.f ? x0v : 0.1f * x0v;
-                            x1v = x1v > 0.f ? x1v : 0.1f * x1v;
-                        }
-                        v[j] = x0v;
-                        w[j] = x1v;
-                    }
+                    const f32x16& q = acc[m][n];
+                    constexpr int Q0 = 0, Q1 = 4;  // register offsets of the two quads inside the pair
+                    const int o = qp * 8;
+                    v01 = f32x2{q[o + Q0 + 0], q[o + Q0 + 1]} * f32x2{s0[0], s0[1]} + f32x2{t0[0], t0[1]};
+                    v23 = f32x2{q[o + Q0 + 2], q[o + Q0 + 3]} * f32x2{s0[2], s0[3]} + f32x2{t0[2], t0[3]};
+                    w01 = f32x2{q[o + Q1 + 0], q[o + Q1 + 1]} * f32x2{s1[0], s1[1]} + f32x2{t1[0], t1[1]};
+                    w23 = f32x2{q[o + Q1 + 2], q[o + Q1 + 3]} * f32x2{s1[2], s1[3]} + f32x2{t1[2], t1[3]};
+                    v01 = leaky2(v01, slope), v23 = leaky2(v23, slope), w01 = leaky2(w01, slope), w23 = leaky2(w23, slope);
                 }
                 const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
                 if constexpr (OUT_F32) {
                     // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
                     if (ok) {
                         float* o = reinterpret_cast<float*>(a.out) + (plane * out_plane_px + pix) * 16;
-                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w[0], w[1], w[2], w[3]);
+                        *reinterpret_cast<float4*>(o + 4 * hh) = make_float4(v01[0], v01[1], v23[0], v23[1]);
+                        *reinterpret_cast<float4*>(o + 8 + 4 * hh) = make_float4(w01[0], w01[1], w23[0], w23[1]);
                     }
                 } else {
-                    const size_t ob = (plane * out_plane_px + pix) * 32 + hh * 16;
                     if constexpr (HAS_RES) {
                         // residual: store layout -> accumulator layout, added in fp32 before the single bf16 rounding
                         uint4 rv;
                         if constexpr (RES_INLINE)
-                            rv = rcur[qp];
+                            rv = rres[t][qp];
                         else
                             rv = rr.r[m][n][qp];
                         auto sx = __builtin_amdgcn_permlane32_swap(rv.x, rv.z, false, false);
                         auto sy = __builtin_amdgcn_permlane32_swap(rv.y, rv.w, false, false);
-                        const uint2 r0v = make_uint2(sx[0], sy[0]), r1v = make_uint2(sx[1], sy[1]);
-                        v[0] += bf2f((uint16_t)(r0v.x & 0xffffu));
-                        v[1] += bf2f((uint16_t)(r0v.x >> 16));
-                        v[2] += bf2f((uint16_t)(r0v.y & 0xffffu));
-                        v[3] += bf2f((uint16_t)(r0v.y >> 16));
-                        w[0] += bf2f((uint16_t)(r1v.x & 0xffffu));
-                        w[1] += bf2f((uint16_t)(r1v.x >> 16));
-                        w[2] += bf2f((uint16_t)(r1v.y & 0xffffu));
-                        w[3] += bf2f((uint16_t)(r1v.y >> 16));
+                        v01 += bf2f2(sx[0]), v23 += bf2f2(sy[0]);
+                        w01 += bf2f2(sx[1]), w23 += bf2f2(sy[1]);
                     }
-                    {
-                        unsigned ax = pack2bf(v[0], v[1]), ay_ = pack2bf(v[2], v[3]);
-                        unsigned bx = pack2bf(w[0], w[1]), by = pack2bf(w[2], w[3]);
-                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
-                        // plain stores: `nt` (streaming) stores were measured slower -- their completion, which the next stage's
-                        // counted DMA wait sits behind, takes longer (first stage of the next item 4.0 -> 5.1 us)
-                        if (ok && !AY_DBGBIT(a, 4)) *reinterpret_cast<uint4*>(a.out + ob) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    const unsigned ax = pack2bf2(v01), ay_ = pack2bf2(v23), bx = pack2bf2(w01), by = pack2bf2(w23);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
+                    // plain stores: `nt` (streaming) stores were measured slower -- their completion, which the next stage's
+                    // counted DMA wait sits behind, takes longer (first stage of the next item 4.0 -> 5.1 us)
+                    if constexpr (DEFER) {
+                        outv[t][qp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                    } else {
+                        if (ok) *reinterpret_cast<uint4*>(a.out + (plane * out_plane_px + pix) * 32 + hh * 16) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                     }
                 }
             }
+            if constexpr (HAS_RES && RES_INLINE) {  // this block's residual registers are free: the block RD ahead
+                if (RD + t < NB) load_res(RD + t, rres[RD + t]);
+            }
+        }
+    }
+    if constexpr (DEFER) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int p = (wn * NT + n) * 32 + c;
+            const int oy = y0 + p / TW, ox = x0 + p % TW;
+            const bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
+            const unsigned vo = ok ? ((unsigned)oy * a.wout + ox) * 32u + hh * 16u : 0x80000000u;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp)
+                    __builtin_amdgcn_raw_buffer_store_b128(outv[n * MT + m][qp], orsrc,
+                                                           vo + (unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes, 0, 0);
         }
     }
 }

@@ -344,6 +344,7 @@ extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const 
     AY_CHECK_ARG(x && w1_packed && scale1 && shift1 && w2_packed && scale2 && shift2 && out, "ay_resblock_fwd_bf16: null");
     AY_CHECK_ARG(ay_resblock_supported(channels), "ay_resblock_fwd_bf16: %d channels unsupported (64 or 128)", channels);
     AY_CHECK_ARG(batch > 0 && h > 0 && w > 0 && x != out, "ay_resblock_fwd_bf16: bad shape / in-place");
+    AY_CHECK_ARG((long long)h * w * 2 * channels < (1ll << 31), "ay_resblock_fwd_bf16: one image exceeds the 2 GiB a buffer descriptor addresses");
     ResBlockArgs s;
     s.x = (const uint8_t*)x;
     s.w1 = (const uint8_t*)w1_packed;
