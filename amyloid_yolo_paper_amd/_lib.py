@@ -14,6 +14,20 @@ class ConvDesc(C.Structure):
         "batch", "cin", "cout", "hin", "win", "hout", "wout", "ksize", "stride", "leaky", "out_f32", "cout_pad")]
 
 
+class PlanOp(C.Structure):
+    """ay_plan_op (include/amyloid_yolo.h)"""
+    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("src2", C.c_int32), ("res", C.c_int32), ("dst", C.c_int32),
+                ("conv", ConvDesc), ("c1", C.c_int32), ("c2", C.c_int32), ("up1", C.c_int32), ("leaky2", C.c_int32),
+                ("num_anchors", C.c_int32), ("num_classes", C.c_int32), ("grid", C.c_int32), ("row_offset", C.c_int32),
+                ("anchors_wh", C.c_float * 12),
+                ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("w2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p)]
+
+
+PLAN_INPUT, PLAN_NONE = -1, -2
+OP_STEM_S2_FUSED, OP_STEM, OP_CONV, OP_RESBLOCK, OP_CONV1X1_CAT, OP_CONCAT_UPSAMPLE, OP_DECODE = 1, 2, 3, 4, 5, 6, 7
+
+
 class AyError(RuntimeError):
     pass
 
@@ -53,6 +67,14 @@ _SIGS = {
     "ay_yolo_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
     "ay_conv1x1_cat_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P, _P, _P, _P]),
     "ay_resblock_supported": (_I, [_I]),
+    "ay_plan_create": (_I, [C.POINTER(PlanOp), _I, C.POINTER(C.c_size_t), _I, _I, _I, C.POINTER(C.c_void_p)]),
+    "ay_plan_destroy": (None, [_P]),
+    "ay_plan_workspace_bytes": (_SZ, [_P]),
+    "ay_plan_value_offset": (_SZ, [_P, _I]),
+    "ay_plan_forward": (_I, [_P, _P, _P, _P, _P]),
+    "ay_plan_forward_timed": (_I, [_P, _P, _P, _P, C.POINTER(C.c_float), _P]),
+    "ay_plan_profile_begin": (_I, [_P, C.POINTER(C.c_ubyte)]),
+    "ay_plan_profile_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ay_resblock_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ay_match_detections": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _P, _P]),
     "ay_ingest_tiles_u8": (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),

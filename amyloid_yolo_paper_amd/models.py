@@ -14,6 +14,7 @@ The ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects in ``module_list`` are parameter 
 the reference's ``state_dict`` schema, optimiser hooks and ``.to(device)``); they are never called.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -97,6 +98,19 @@ def _pad_to(v, m):
     return (v + m - 1) // m * m
 
 
+class _Plan:
+    """owner of an ``ay_plan`` handle and its workspace"""
+
+    def __init__(self, handle, workspace, ops, value_bytes):
+        self.handle, self.workspace, self.ops, self.value_bytes = handle, workspace, ops, value_bytes
+
+    def __del__(self):
+        try:
+            _lib.lib().ay_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class Darknet(nn.Module):
     """YOLOv3 detector; see module docstring."""
 
@@ -121,6 +135,7 @@ class Darknet(nn.Module):
         self.stem_mode = "fused_bf16"   # "fp32": separate fp32 stem kernel (layer 0 output materialised)
         self.fold_routes = True         # route [upsampled | direct] -> 1x1 conv without materialising the concatenation
         self.fuse_blocks = True         # fused residual-block kernel for the C=64/128 blocks (False: two conv launches)
+        self.use_plan = os.environ.get("AY_USE_PLAN", "1") != "0"  # bf16 inference: the whole network issued by the native plan (ay_plan_forward)
         self.box_loss = "mse"           # "giou": 1 - GIoU replaces the four squared-error box terms (new feature; the
                                         # reference has only the MSE form, models.py:183-186)
 
@@ -383,6 +398,13 @@ class Darknet(nn.Module):
                     bufs[i] = torch.empty(B, _pad_to(c, 16) // 16, h, h, 16, device=dev, dtype=torch.bfloat16)
             return bufs[i]
 
+        prof = getattr(self, "profile_layers", None)  # bench.py: bracket these conv launches with HIP events
+        if bf16 and self.use_plan and not self.keep_layer_outputs and prof is None:
+            # the whole network from native code: one call, activations in one arena with lifetime reuse
+            plan = self._plan(B, S, prep, dev)
+            check(L.ay_plan_forward(plan.handle, ptr(x), ptr(plan.workspace), ptr(out), st), "ay_plan_forward")
+            return out
+
         # values: ("t", tensor) materialised, ("up", layer) lazily upsampled view of another layer
         val = {}
 
@@ -403,7 +425,6 @@ class Darknet(nn.Module):
             return o
 
         row = 0
-        prof = getattr(self, "profile_layers", None)  # bench.py: bracket these conv launches with HIP events
         for i, e in enumerate(self._graph):
             t = e["type"]
             if t == "convolutional":
@@ -517,6 +538,179 @@ class Darknet(nn.Module):
         if self.keep_layer_outputs:
             self.layer_outputs = {i: v[1] for i, v in val.items() if v[0] == "t"}
         return out
+
+    # ------------------------------------------------------------------ native plan
+    def _lower(self, B, S, prep):
+        """The bf16 walk of ``forward_device`` with symbolic values: the op list (``_lib.PlanOp``) and the byte size of every
+        value, for ``ay_plan_create``.  Same decisions as the per-layer walk (fused stem, fused block, route folded into the 1x1
+        loader, lazy upsample), so both issue the same kernels with the same arguments."""
+        assert self.precision == "bf16"
+        ops, vbytes, val = [], [], {}
+        N = self.num_boxes(S)
+
+        def size_of(i):
+            return S >> self._graph[i]["log2_down"] if i >= 0 else S
+
+        def new_value(i, f32=False):
+            c, h = self._graph[i]["channels"], size_of(i)
+            vbytes.append(B * (_pad_to(c, 32) // 16) * h * h * 16 * 4 if f32 else B * (_pad_to(c, 16) // 16) * h * h * 16 * 2)
+            return len(vbytes) - 1
+
+        def op(kind, **kw):
+            o = _lib.PlanOp()
+            o.kind = kind
+            o.src = o.src2 = o.res = o.dst = _lib.PLAN_NONE
+            for k, v in kw.items():
+                setattr(o, k, v)
+            ops.append(o)
+            return o
+
+        def params(o, p, second=None):
+            o.w, o.scale, o.shift = p["packed"].data_ptr() if "packed" in p else p["w"].data_ptr(), p["scale"].data_ptr(), p["shift"].data_ptr()
+            if second is not None:
+                o.w2, o.scale2, o.shift2 = second["packed"].data_ptr(), second["scale"].data_ptr(), second["shift"].data_ptr()
+
+        def resolve(i):
+            v = val[i]
+            if v[0] == "t":
+                return v[1]
+            src = resolve(v[1])  # lazy upsample -> materialise
+            h = size_of(i)
+            dst = new_value(i)
+            op(_lib.OP_CONCAT_UPSAMPLE, src=src, dst=dst, c1=self._graph[i]["channels"], up1=1, c2=0,
+               conv=ConvDesc(B, 0, 0, h, h, h, h, 1, 1, 0, 0, 0))
+            val[i] = ("t", dst)
+            return dst
+
+        row = 0
+        for i, e in enumerate(self._graph):
+            t = e["type"]
+            if t == "convolutional":
+                if i in val and val[i][0] == "fused":
+                    continue  # second half of a fused residual block
+                p = prep["layers"][i]
+                hin, hout = size_of(e["src"]), size_of(i)
+                fuse = e["fuse_into_shortcut"]
+                is_head = not e["bn"] and not e["leaky"]
+                d = ConvDesc(B, e["cin"], e["cout"], hin, hin, hout, hout, e["k"], e["stride"], int(e["leaky"]), int(is_head), p["cpad"])
+                tgt = i + 1 if fuse else i
+                if e["fuse_block"] and self.fuse_blocks:
+                    p2, e2 = prep["layers"][i + 1], self._graph[i + 1]
+                    src = resolve(e["src"])
+                    dst = new_value(i + 2)
+                    o = op(_lib.OP_RESBLOCK, src=src, dst=dst, conv=d, leaky2=int(e2["leaky"]))
+                    params(o, p, p2)
+                    val[i] = val[i + 1] = ("fused", None)
+                    val[i + 2] = ("t", dst)
+                    continue
+                if i == 0 and self._fuse_stem and self.stem_mode == "fused_bf16":
+                    val[i] = ("fused", None)
+                    continue
+                if i == 1 and val.get(0, (None,))[0] == "fused":
+                    p0 = prep["layers"][0]
+                    dst = new_value(tgt)
+                    o = op(_lib.OP_STEM_S2_FUSED, dst=dst, leaky2=int(e["leaky"]),
+                           conv=ConvDesc(B, 3, 32, S, S, S, S, 3, 1, int(self._graph[0]["leaky"]), 0, 32))
+                    o.w, o.scale, o.shift = p0["w0_bf16"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr()
+                    o.w2, o.scale2, o.shift2 = p["packed"].data_ptr(), p["scale"].data_ptr(), p["shift"].data_ptr()
+                    val[i] = ("t", dst)
+                    continue
+                if p["stem"]:
+                    dst = new_value(tgt)
+                    o = op(_lib.OP_STEM, dst=dst, conv=d)
+                    params(o, p)
+                elif e["src"] >= 0 and val[e["src"]][0] == "catup":
+                    ra, rb = val[e["src"]][1]
+                    s1 = resolve(val[ra][1])  # half-resolution source of the lazy upsample
+                    s2 = resolve(rb)
+                    dst = new_value(tgt)
+                    o = op(_lib.OP_CONV1X1_CAT, src=s1, src2=s2, dst=dst, conv=d, c1=self._graph[ra]["channels"])
+                    params(o, p)
+                else:
+                    if e["src"] < 0:
+                        raise NotImplementedError("bf16 path expects the 3->32 3x3 stem as layer 0")
+                    src = resolve(e["src"])
+                    res = resolve(self._graph[i + 1]["b"]) if fuse else _lib.PLAN_NONE
+                    dst = new_value(tgt, f32=is_head)
+                    o = op(_lib.OP_CONV, src=src, res=res, dst=dst, conv=d)
+                    params(o, p)
+                    o._layer = i
+                val[i] = ("t", dst)
+                if fuse:
+                    val[i] = ("fused", None)
+                    val[i + 1] = ("t", dst)
+            elif t == "shortcut":
+                if i not in val:
+                    raise NotImplementedError(f"layer {i}: unfused shortcut (a source other than the preceding conv)")
+            elif t == "upsample":
+                val[i] = ("up", e["src"])
+            elif t == "route":
+                srcs = e["srcs"]
+                if len(srcs) == 1:
+                    val[i] = val[srcs[0]] if val[srcs[0]][0] != "up" else ("t", resolve(srcs[0]))
+                elif len(srcs) == 2:
+                    if self._cat_foldable(i, val):
+                        val[i] = ("catup", srcs)
+                    else:
+                        a, b_ = srcs
+                        up = val[a][0] == "up"
+                        s1 = resolve(val[a][1]) if up else resolve(a)
+                        s2 = resolve(b_)
+                        h = size_of(i)
+                        dst = new_value(i)
+                        op(_lib.OP_CONCAT_UPSAMPLE, src=s1, src2=s2, dst=dst, c1=self._graph[a]["channels"], up1=int(up),
+                           c2=self._graph[b_]["channels"], conv=ConvDesc(B, 0, 0, h, h, h, h, 1, 1, 0, 0, 0))
+                        val[i] = ("t", dst)
+                else:
+                    raise NotImplementedError("route with more than two sources")
+            elif t == "yolo":
+                y = self.module_list[i][0]
+                head = resolve(e["src"])
+                G = size_of(i)
+                assert y.num_anchors <= 6
+                o = op(_lib.OP_DECODE, src=head, num_anchors=y.num_anchors, num_classes=y.num_classes, grid=G, row_offset=row,
+                       conv=ConvDesc(B, 0, 0, G, G, G, G, 1, 1, 0, 0, 0))
+                for k, v in enumerate(float(v) for a in y.anchors for v in a):
+                    o.anchors_wh[k] = v
+                y.grid_size, y.img_dim = G, S
+                row += y.num_anchors * G * G
+                val[i] = ("t", head)
+        assert row == N
+        return ops, vbytes
+
+    def _plan(self, B, S, prep, dev):
+        """(plan handle, workspace tensor, op list) for this batch shape; plans live in ``prep`` and die with it (new weights)."""
+        plans = prep.setdefault("plans", {})
+        key = (B, S, self.fuse_blocks, self.fold_routes, self.stem_mode, tuple(self.fuse_block_channels))
+        if key not in plans:
+            L = _lib.lib()
+            ops, vbytes = self._lower(B, S, prep)
+            arr = (_lib.PlanOp * len(ops))(*ops)
+            vb = (C.c_size_t * len(vbytes))(*vbytes)
+            handle = C.c_void_p()
+            check(L.ay_plan_create(arr, len(ops), vb, len(vbytes), S, self.num_boxes(S), C.byref(handle)), "ay_plan_create")
+            ws = torch.empty(L.ay_plan_workspace_bytes(handle), device=dev, dtype=torch.uint8)
+            plans[key] = _Plan(handle, ws, ops, sum(vbytes))
+        return plans[key]
+
+    def plan_profile_begin(self, B, S, layers=None):
+        """start recording HIP event pairs around the ops of ``layers`` (conv layer indices; None = every op) in the plan of
+        this batch shape (bench.py: roofline of the 3x3 family)"""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        plan = self._plan(B, S, self._prepare(dev), dev)
+        sel = None
+        if layers is not None:
+            sel = (C.c_ubyte * len(plan.ops))(*[int(getattr(o, "_layer", None) in layers) for o in plan.ops])
+        check(_lib.lib().ay_plan_profile_begin(plan.handle, sel), "ay_plan_profile_begin")
+
+    def plan_profile_end(self, B, S):
+        """-> ([(layer index | None, op kind, ms summed over the recorded forwards)], number of forwards)"""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        plan = self._plan(B, S, self._prepare(dev), dev)
+        ms = (C.c_float * len(plan.ops))()
+        n = C.c_int(0)
+        check(_lib.lib().ay_plan_profile_end(plan.handle, ms, C.byref(n)), "ay_plan_profile_end")
+        return [(getattr(o, "_layer", None), o.kind, float(ms[k])) for k, o in enumerate(plan.ops)], n.value
 
     def _cat_foldable(self, i, val):
         """route i = [lazily upsampled a | b] whose only consumer is the next layer, a 1x1 bf16 conv block the dual-source

@@ -144,8 +144,12 @@ def main():
     torch.cuda.synchronize()
     if USE_DIST:
         dist.barrier()
-    model.profile_layers = None if a.no_layer_events else set(fam)
-    model.profile_events = []
+    if not a.no_layer_events:
+        if model.use_plan:  # HIP event pairs around the family's launches, recorded by the native plan on the stream it issues to
+            model.plan_profile_begin(a.batch, a.size, set(fam))
+        else:               # AY_USE_PLAN=0: the per-layer walk brackets the same launches itself
+            model.profile_layers = set(fam)
+            model.profile_events = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -159,8 +163,18 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    events = model.profile_events
-    model.profile_layers = None
+    events = []
+    if not a.no_layer_events and model.use_plan:
+        per_op, n_fwd = model.plan_profile_end(a.batch, a.size)
+        assert n_fwd == a.steps
+        famset = set(fam)
+        events = [ms for layer, kind, ms in per_op if layer in famset]   # per family launch: ms summed over the timed steps
+    elif not a.no_layer_events:
+        by_layer = {}
+        for layer, s, e in model.profile_events:
+            by_layer[layer] = by_layer.get(layer, 0.0) + s.elapsed_time(e)
+        events = list(by_layer.values())
+        model.profile_layers = None
 
     rows, keep, count, cand = res
     cnt, cnd = count.cpu().numpy(), cand.cpu().numpy()
@@ -181,8 +195,8 @@ def main():
     }
     if rank == 0:
         if events:
-            ms = sum(s.elapsed_time(e) for _, s, e in events)
-            launches = len(events)
+            ms = sum(events)
+            launches = len(events) * a.steps
             achieved = fam_flops * a.steps / (ms * 1e-3) / 1e12
             traffic = None
             try:

@@ -248,6 +248,57 @@ int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int 
  * (desc as in the forward; cout_pad = channels of dz's planes) */
 int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream);
 
+/* ---- inference plan: Darknet.forward (models.py:237-255) lowered to a flat op list ------------------------------
+ * The host lowers the cfg graph once (which layers fuse, which routes fold into a loader) and hands the ops over; the
+ * library lays the layer outputs ("values") out in ONE caller-allocated workspace -- a value's bytes are reused once its
+ * last reader has been issued (first-fit over lifetimes; everything is stream-ordered) -- and ay_plan_forward issues the
+ * whole network: one C call per batch instead of ~85.  Weight/scale/shift pointers are device memory owned by the caller
+ * and must outlive the plan.  src/res/dst are value ids (0 .. n_values-1); AY_PLAN_INPUT names the network input. */
+#define AY_PLAN_INPUT (-1)
+#define AY_PLAN_NONE (-2)
+enum {
+    AY_OP_STEM_S2_FUSED = 1, /* ay_stem_s2_fused_fwd: input -> dst; w = stem filters bf16, w2 = packed layer-1 filters */
+    AY_OP_STEM = 2,          /* ay_stem_conv_fwd: input -> dst; w = OIHW fp32 filters */
+    AY_OP_CONV = 3,          /* ay_conv_fwd_bf16: src (+ res) -> dst */
+    AY_OP_RESBLOCK = 4,      /* ay_resblock_fwd_bf16: src -> dst; (w, scale, shift, conv.leaky) = 1x1, (w2, ..2, leaky2) = 3x3 */
+    AY_OP_CONV1X1_CAT = 5,   /* ay_conv1x1_cat_fwd_bf16: src = half-resolution source (c1 channels), src2 = direct source */
+    AY_OP_CONCAT_UPSAMPLE = 6, /* ay_concat_upsample_bf16: src (c1 channels, up1) [+ src2 (c2 channels)] -> dst, conv.hout x wout */
+    AY_OP_DECODE = 7         /* ay_yolo_decode of a blocked-f32 head: src -> rows [row_offset, ..) of the output */
+};
+typedef struct ay_plan_op {
+    int32_t kind;
+    int32_t src, src2, res, dst;   /* value ids; AY_PLAN_NONE where unused */
+    ay_conv_desc conv;             /* shapes (all kinds use batch/hout/wout; RESBLOCK: cin = channels) */
+    int32_t c1, c2, up1;           /* CONV1X1_CAT: c1; CONCAT_UPSAMPLE: c1, c2, up1 */
+    int32_t leaky2;                /* STEM_S2_FUSED / RESBLOCK: activation of the second convolution */
+    int32_t num_anchors, num_classes, grid, row_offset; /* DECODE */
+    float anchors_wh[12];          /* DECODE: up to 6 anchors (w,h) in pixels */
+    const void* w;
+    const float* scale;
+    const float* shift;
+    const void* w2;
+    const float* scale2;
+    const float* shift2;
+} ay_plan_op;
+typedef struct ay_plan ay_plan;
+/* value_bytes[i] = size of value i.  Fails (AY_ERR_ARG) on a value read before it is written or never written. */
+int ay_plan_create(const ay_plan_op* ops, int n_ops, const size_t* value_bytes, int n_values, int img_dim, int n_total_rows,
+                   ay_plan** out_plan);
+void ay_plan_destroy(ay_plan* plan);
+size_t ay_plan_workspace_bytes(const ay_plan* plan);       /* 256-byte aligned arena the caller allocates */
+size_t ay_plan_value_offset(const ay_plan* plan, int value); /* where a value lives in the arena (tests) */
+/* x: [B][3][S][S] fp32 NCHW; out_rows: [B][n_total_rows][5+C] fp32.  Stream-ordered, no host synchronisation. */
+int ay_plan_forward(const ay_plan* plan, const float* x_nchw, void* workspace, float* out_rows, ay_stream_t stream);
+/* Profiling without a host synchronisation inside the measured region: between begin and end every ay_plan_forward records
+ * an event pair around each selected op (op_selected[n_ops] of 0/1, NULL = all; an event record costs the stream a few
+ * microseconds), on the stream it issues to; end waits for them and returns, per op, the time summed over the recorded
+ * forwards (0 for unselected ops).  A plan is driven by one host thread at a time. */
+int ay_plan_profile_begin(ay_plan* plan, const unsigned char* op_selected);
+int ay_plan_profile_end(ay_plan* plan, float* op_ms_sum /* n_ops */, int* n_forwards);
+/* one forward with a HIP event pair around every op on `stream`; synchronises the stream and fills op_ms[n_ops] */
+int ay_plan_forward_timed(const ay_plan* plan, const float* x_nchw, void* workspace, float* out_rows, float* op_ms,
+                          ay_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

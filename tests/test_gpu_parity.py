@@ -554,3 +554,49 @@ def test_conv1x1_cat_kernel(dev, case):
     err = (got.cpu() - ref).abs()
     assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-3).all()), float(err.max())
 
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(fuse_blocks=False, fold_routes=False), dict(stem_mode="fp32")], ids=str)
+def test_native_plan_equals_per_layer_walk(tmp_cfg_dir, dev, opts):
+    """ay_plan_forward (graph lowered once, values in one arena with lifetime reuse, the network issued from C) gives the
+    same rows, bit for bit, as the per-layer ctypes walk: same kernels, same arguments.  Repeats show that reusing the
+    arena across batches and across differently shaped plans leaves nothing behind."""
+    m, _ = build_models(3, tmp_cfg_dir, dev, "bf16")
+    saved = {k: getattr(m, k) for k in ("fuse_blocks", "fold_routes", "stem_mode", "use_plan")}
+    try:
+        for k, v in opts.items():
+            setattr(m, k, v)
+        for S, B, start in ((416, 3, 20), (128, 2, 5), (416, 3, 31)):
+            x = torch.from_numpy(gc.model_inputs(S, B, start))
+            m.use_plan = False
+            ref = m(x).clone()
+            m.use_plan = True
+            for rep in range(2):
+                out = m(x)
+                assert torch.equal(out, ref), (S, rep)
+        prep = m._prepare(dev)
+        plan = m._plan(3, 416, prep, dev)
+        per_layer = sum(t.numel() * t.element_size() for k, t in m._act_bufs[("bf16", 3, 416)].items() if isinstance(k, int))
+        assert plan.workspace.numel() < 0.3 * per_layer          # the per-layer walk keeps every layer output alive
+        # timed variant: one positive duration per op, the 3x3 layers dominating
+        L = _lib.lib()
+        xd = torch.from_numpy(gc.model_inputs(416, 3, 20)).to(dev)
+        out = torch.empty(3, m.num_boxes(416), 8, device=dev)
+        ms = (C.c_float * len(plan.ops))()
+        check(L.ay_plan_forward_timed(plan.handle, ptr(xd), ptr(plan.workspace), ptr(out), ms, _lib.stream_ptr()), "timed")
+        assert all(v > 0 for v in ms) and len(ms) == len(plan.ops)
+        m.use_plan = False
+        assert torch.equal(out.cpu(), m(torch.from_numpy(gc.model_inputs(416, 3, 20))))
+        # stream-ordered profiling of selected layers across several forwards
+        m.use_plan = True
+        convs = {getattr(o, "_layer", None) for o in plan.ops} - {None}
+        pick = set(sorted(convs)[:5])
+        m.plan_profile_begin(3, 416, pick)
+        for _ in range(3):
+            m.forward_device(torch.from_numpy(gc.model_inputs(416, 3, 20)))
+        per_op, n_fwd = m.plan_profile_end(3, 416)
+        assert n_fwd == 3 and len(per_op) == len(plan.ops)
+        assert all((ms > 0) == (layer in pick) for layer, kind, ms in per_op)
+    finally:
+        for k, v in saved.items():
+            setattr(m, k, v)
