@@ -75,3 +75,15 @@ def test_forward_without_gpu_raises(tmp_cfg_dir):
     m = Darknet(cfg_gen.write_cfg(2, tmp_cfg_dir)).eval()
     with pytest.raises(_lib.AyError):
         m(torch.zeros(1, 3, 64, 64))
+
+
+def test_conv_rejects_images_beyond_the_descriptor_range():
+    """The bf16 epilogue addresses one image's output through a buffer descriptor (32-bit offsets, out-of-image lanes at
+    0x80000000): the entry point must refuse an image whose output exceeds 2 GiB instead of wrapping.  Host-side check, no GPU."""
+    import ctypes as C
+    from amyloid_yolo_paper_amd._lib import ConvDesc
+    L = _lib.lib()
+    dummy = C.c_void_p(0x1000)
+    d = ConvDesc(1, 64, 64, 16384, 16384, 16384, 16384, 3, 1, 1, 0, 64)      # 16384^2 x 64 ch x 2 B = 32 GiB per image
+    rc = L.ay_conv_fwd_bf16(C.byref(d), dummy, dummy, dummy, dummy, None, dummy, None)
+    assert rc == -1 and b"2 GiB" in L.ay_last_error()
