@@ -78,6 +78,7 @@ _SIGS = {
     "ay_resblock_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ay_match_detections": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _P, _P]),
     "ay_ingest_tiles_u8": (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
+    "ay_ingest_region_tiles_u8": (_I, [_P, _I, _I, _SZ, _I, _I, _I, _I, _I, _P, _P]),
     "ay_build_targets_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ay_build_targets": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ay_yolo_loss_giou_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),

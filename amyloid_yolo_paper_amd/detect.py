@@ -44,7 +44,12 @@ def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_p
                 out[idx] = ingest_tiles_device(torch.stack([imgs[i] for i in idx]), img_size)
             imgs = out
         with torch.no_grad():
-            dets = non_max_suppression(model(imgs), conf_thres, nms_thres)
+            if device_ingest:
+                # the [B,N,5+C] rows stay on the device: only the detections come back (the reference's `model(x)` returns the
+                # full CPU tensor, 2 MB per 1024^2 tile, which nothing downstream of NMS reads)
+                dets = [None if d is None else d.cpu() for d in non_max_suppression(model.forward_device(imgs), conf_thres, nms_thres)]
+            else:
+                dets = non_max_suppression(model(imgs), conf_thres, nms_thres)
         now = time.time()
         if verbose:
             print("\t+ Batch %d, Inference Time: %s" % (batch_i, datetime.timedelta(seconds=now - prev)))

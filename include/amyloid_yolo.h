@@ -223,6 +223,14 @@ int ay_match_detections(const float* rows, const int32_t* count, int batch, int 
 int ay_ingest_tiles_u8(const void* img_hwc_u8, int batch, int h, int w, int out_size, float pad_value, float* out_nchw,
                        ay_stream_t stream);
 
+/* WSI -> tile streaming (crop.py:13-25,44-47): tile t = (ty, tx) of the tile_size grid dzsave(layout='google')
+ * lays over the slide, cut out of a resident uint8 HWC region (rows `row_stride_bytes` apart; region_h x region_w source pixels),
+ * edge tiles padded with the background 255; shrink 2 = the 40x -> 20x halving first (2x2 mean, round half up; the grid then lies
+ * on the region_h/2 x region_w/2 image); then x/255 and the nearest resize to out_size as in ay_ingest_tiles_u8.
+ * out [tiles_y*tiles_x][3][out_size][out_size] fp32. */
+int ay_ingest_region_tiles_u8(const void* region_hwc_u8, int region_h, int region_w, size_t row_stride_bytes, int shrink,
+                              int tile, int tiles_y, int tiles_x, int out_size, float* out_nchw, ay_stream_t stream);
+
 /* ---- training step, bf16 MFMA path (blocked bf16 activations and activation gradients) ------------- */
 
 /* Train-mode BatchNorm + LeakyReLU (+ fused shortcut add of `skip`) around the MFMA convolution: statistics pass (fp64

@@ -600,3 +600,53 @@ def test_native_plan_equals_per_layer_walk(tmp_cfg_dir, dev, opts):
     finally:
         for k, v in saved.items():
             setattr(m, k, v)
+
+
+@pytest.mark.parametrize("case", [(70, 100, 32, 32, 1), (70, 100, 32, 24, 1), (133, 97, 32, 32, 2), (64, 64, 16, 40, 2)], ids=str)
+def test_region_tiles_device(dev, case):
+    """ay_ingest_region_tiles_u8 (§8f N4) == the oracle's padded dzsave grid + N1 chain, bit for bit (integer mean, one fp32
+    division), for the whole raster as one region and streamed strip by strip through RegionTileStream."""
+    from oracle.ingest_oracle import region_tiles
+    from amyloid_yolo_paper_amd.wsi import RegionTileStream
+    H, W, tile, S, shrink = case
+    r = np.random.default_rng(H + W).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    want, (ty, tx) = region_tiles(r, tile, S, shrink)
+    L = _lib.lib()
+    rd = torch.from_numpy(r).to(dev)
+    out = torch.empty(ty * tx, 3, S, S, device=dev)
+    check(L.ay_ingest_region_tiles_u8(ptr(rd), H, W, W * 3, shrink, tile, ty, tx, S, ptr(out), _lib.stream_ptr()), "region")
+    assert torch.equal(out.cpu(), want)
+    got, coords = [], []
+    stream = RegionTileStream(r, tile, S, shrink)
+    assert (stream.tiles_y, stream.tiles_x) == (ty, tx)
+    for tiles, cs in stream:
+        got.append(tiles.cpu())
+        coords += cs
+    assert coords == [(j, i) for j in range(ty) for i in range(tx)]
+    assert torch.equal(torch.cat(got), want)
+
+
+def test_detect_region_equals_per_tile_detection(tmp_cfg_dir, dev):
+    """detect_region over a raster == model + non_max_suppression on each oracle-cut tile, boxes moved to slide coordinates."""
+    from oracle.ingest_oracle import region_tiles
+    from amyloid_yolo_paper_amd.wsi import detect_region
+    from amyloid_yolo_paper_amd.utils import non_max_suppression
+    m, _ = build_models(3, tmp_cfg_dir, dev, "bf16")
+    S, tile = 128, 192
+    tiles = (gc.model_inputs(S, 6, 40) * 255).astype(np.uint8).transpose(0, 2, 3, 1)         # six synthetic tiles
+    big = np.kron(np.ones((1, 1, 1), np.uint8), np.concatenate([np.concatenate(list(tiles[:3]), 1), np.concatenate(list(tiles[3:]), 1)], 0))
+    raster = np.repeat(np.repeat(big, 2, 0), 2, 1)[: 2 * S + 77, : 3 * 2 * S - 50]           # 256-px content, ragged edges
+    res = detect_region(m, raster, tile=tile, img_size=S, conf_thres=0.5, nms_thres=0.4, batch_size=4)
+    want, (ty, tx) = region_tiles(raster, tile, S)
+    det = non_max_suppression(m(want), 0.5, 0.4)
+    expect = {}
+    for t, d in enumerate(det):
+        if d is not None:
+            d = d.clone()
+            d[:, :4] *= tile / S
+            d[:, [0, 2]] += (t % tx) * tile
+            d[:, [1, 3]] += (t // tx) * tile
+            expect[(t // tx, t % tx)] = d
+    assert len(expect) > 0 and {(a, b_) for a, b_, _ in res} == set(expect)
+    for a, b_, d in res:
+        assert torch.equal(d, expect[(a, b_)])
