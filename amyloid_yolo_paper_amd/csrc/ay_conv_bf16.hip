@@ -606,7 +606,13 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     constexpr int NPIECE = NK * (PX_PIECES + W_PIECES);     // + the piece(s) that carry this item's scale/shift
     constexpr int SSP = BN > 128 ? 2 : 1;                   // BN <= 128: one piece [scale | shift]; 256: a scale piece, a shift piece
     constexpr int SSR = SSP * 1024;                         // bytes of one scale/shift region
-    constexpr int PW = (NPIECE + SSP + 7) / 8;              // pieces per wave per stage (dummy-padded)
+    // Piece i of a wave has the same KIND in every wave: i < PWP pixel pieces (global piece i*8 + wave of the pixel slabs), the
+    // rest filter-side (filter pieces, then the scale/shift piece(s)); each list is padded to a multiple of 8 with dummy pieces
+    // that copy zeros into a scratch KiB.  With the kind depending on the wave (one list i*8 + wave over all pieces) every DMA
+    // issue went through ~6 scalar branches; now the unrolled issue code is straight-line with a few scalar selects.
+    constexpr int PWP = (NK * PX_PIECES + 7) / 8;
+    constexpr int PWW = (NK * W_PIECES + SSP + 7) / 8;
+    constexpr int PW = PWP + PWW;                           // pieces per wave per stage (dummy-padded)
     constexpr int DUMMY_BASE = NBUF * BUF_BYTES;
     constexpr int SS_BASE = DUMMY_BASE + 1024;              // 4 x 1 KiB [scale 128][shift 128], by item index & 3 (the loader
                                                             // runs at most NBUF-1 <= 2 items ahead of the epilogue)
@@ -706,53 +712,52 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             ld_ss = a.scale + (size_t)cg * BN + lane * 4;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int q = i * 8 + wave;
             int off = -1, off1 = -1;
-            if (q < NK * PX_PIECES) {
+            if (i < PWP) {
+                const int q = i * 8 + wave;  // pixel piece; q >= NK * PX_PIECES: padding
                 const int kk = q / PX_PIECES, j = q % PX_PIECES;
                 const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX]
                 const int h = u / IN_PIX, P = u % IN_PIX;
                 const int iy = y0 * STRIDE - PAD + P / IN_W;
                 const int ix = x0 * STRIDE - PAD + P % IN_W;
-                if (h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
+                if (q < NK * PX_PIECES && h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
                     off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
                     off1 = (int)(kk * in_plane1) + ((iy >> 1) * (a.win >> 1) + (ix >> 1)) * 32 + h * 16;
                 }
-            } else if (q < NPIECE) {
-                const int qq = q - NK * PX_PIECES;
+            } else {
+                const int qq = (i - PWP) * 8 + wave;   // filter piece; qq >= NK * W_PIECES: scale/shift or padding
                 const int u = qq * 64 + lane;          // unit inside the stage's filter image [kk][tap][half][BN]
                 const int r = u % BN, th = u / BN;
-                off = (th * CP + r) * 16;
+                if (qq < NK * W_PIECES) off = (th * CP + r) * 16;
             }
             src_off[i] = off;
             if constexpr (CAT) src_off1[i] = off1;
         }
     };
     auto issue_piece = [&](int i, int buf) __attribute__((always_inline)) {  // DMA piece i of the loader's current stage into ring slot `buf`
-        const bool from1 = CAT && ld_s < s1_stages;  // wave-uniform
-        const uint8_t* sp = from1 ? ld_src1 + (size_t)ld_s * NK * in_plane1 : ld_src + (size_t)(ld_s - s1_stages) * NK * in_plane;
-        const uint8_t* wp = ld_w + (size_t)ld_s * w_stage_stride;
-        const int q = i * 8 + wave;  // wave-uniform
+        const uint8_t* zp = zero_page + (lane & 3) * 16;
         const uint8_t* g;
         int dst;
-        if (q < NK * PX_PIECES) {
-            const int kk = q / PX_PIECES, j = q % PX_PIECES;
-            g = sp + (from1 ? src_off1[CAT ? i : 0] : src_off[i]);
-            dst = buf * BUF_BYTES + kk * PIX_SLAB + j * 1024;
-        } else if (q < NPIECE) {
-            g = wp + src_off[i];
-            dst = buf * BUF_BYTES + W_BASE + (q - NK * PX_PIECES) * 1024;
-        } else if (q == NPIECE) {
-            g = reinterpret_cast<const uint8_t*>(ld_ss);
-            dst = SS_BASE + ld_par * SSR;
-        } else if (SSP == 2 && q == NPIECE + 1) {
-            g = reinterpret_cast<const uint8_t*>(ld_ss + (a.shift - a.scale));  // same lane offset in the shift array
-            dst = SS_BASE + ld_par * SSR + 1024;
+        if (i < PWP) {  // `i` is a constant after unrolling: one kind per call site, the rest is selects
+            const bool from1 = CAT && ld_s < s1_stages;  // wave-uniform
+            const uint8_t* sp = from1 ? ld_src1 + (size_t)ld_s * NK * in_plane1 : ld_src + (size_t)(ld_s - s1_stages) * NK * in_plane;
+            const int q = i * 8 + wave;  // wave-uniform
+            const int off0 = src_off[i], off1 = src_off1[CAT ? i : 0];  // both read by value: a select between the arrays
+            const int off = from1 ? off1 : off0;                        // puts them on the stack (seen: 64 B of scratch)
+            g = off >= 0 ? sp + off : zp;
+            dst = q < NK * PX_PIECES ? buf * BUF_BYTES + (q / PX_PIECES) * PIX_SLAB + (q % PX_PIECES) * 1024 : DUMMY_BASE;
         } else {
-            g = zero_page;
-            dst = DUMMY_BASE;
+            const uint8_t* wp = ld_w + (size_t)ld_s * w_stage_stride;
+            const int qq = (i - PWP) * 8 + wave;  // wave-uniform
+            const bool is_w = qq < NK * W_PIECES;
+            const bool is_ss = qq >= NK * W_PIECES && qq < NK * W_PIECES + SSP;
+            // scale/shift piece(s): lane pointer ld_ss (nullptr: lane carries nothing); the shift array at the same lane offset
+            const float* ssp = (SSP == 2 && qq == NK * W_PIECES + 1) ? ld_ss + (a.shift - a.scale) : ld_ss;
+            const uint8_t* gss = (is_ss && ld_ss != nullptr) ? reinterpret_cast<const uint8_t*>(ssp) : zp;
+            g = is_w ? wp + src_off[i] : gss;
+            dst = is_w ? buf * BUF_BYTES + W_BASE + qq * 1024
+                       : (is_ss ? SS_BASE + ld_par * SSR + (qq - NK * W_PIECES) * 1024 : DUMMY_BASE);
         }
-        if (q >= NPIECE && q < NPIECE + SSP ? ld_ss == nullptr : src_off[i] < 0) g = zero_page + (lane & 3) * 16;
         dma16(g, lds_base + __builtin_amdgcn_readfirstlane(dst));
     };
     auto advance_loader = [&]() __attribute__((always_inline)) {

@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 L=amyloid_yolo_paper_amd/libamyloid_yolo_hip.so
-cp $L ab/lib_keep.so
+mkdir -p ab; cp $L ab/lib_keep.so
 for rep in 1 2; do
   for v in "$@"; do
     cp ab/lib_$v.so $L
