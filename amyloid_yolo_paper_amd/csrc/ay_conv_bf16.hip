@@ -718,10 +718,13 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 const int kk = q / PX_PIECES, j = q % PX_PIECES;
                 const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX]
                 const int h = u / IN_PIX, P = u % IN_PIX;
-                const int iy = y0 * STRIDE - PAD + P / IN_W;
-                const int ix = x0 * STRIDE - PAD + P % IN_W;
-                if (q < NK * PX_PIECES && h < 2 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
-                    off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
+                int iy = y0 * STRIDE - PAD + P / IN_W;
+                int ix = x0 * STRIDE - PAD + P % IN_W;
+                bool inside = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+                int img = 0;  // canvas mode: this lane's image; its planes lie img * (cin/16) planes further on
+                if (!CAT && a.canvas_gx) inside = canvas_px(a, iy, ix, img, iy, ix);
+                if (q < NK * PX_PIECES && h < 2 && inside) {
+                    off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16 + img * (a.cin / 16) * (int)in_plane;
                     off1 = (int)(kk * in_plane1) + ((iy >> 1) * (a.win >> 1) + (ix >> 1)) * 32 + h * 16;
                 }
             } else {
@@ -958,6 +961,15 @@ int conv_num_cus() {
     return n;
 }
 
+// canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers whose images fit at least twice across a tile and
+// whose tensors stay below 2 GiB (per-lane image offsets are 32-bit); AY_CANVAS=0 turns it off
+static bool canvas_ok(const ay_conv_desc* d, int tw) {
+    static const int on = getenv("AY_CANVAS") ? atoi(getenv("AY_CANVAS")) : 1;
+    const long long px = (long long)d->hout * d->wout;
+    return on && !d->out_f32 && d->hin == d->hout && d->win == d->wout && 2 * (d->wout + 1) <= tw && d->batch > 1 &&
+           px * d->batch * d->cin * 2 < (1ll << 31) && px * d->batch * d->cout_pad * 2 < (1ll << 31);
+}
+
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
 static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
                   const void* residual, void* out, hipStream_t st) {
@@ -999,7 +1011,16 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         static const int dyn1 = getenv("AY_DYN1") ? atoi(getenv("AY_DYN1")) : 1;
         if (dynamic && deal_base && (KS == 3 || dyn1)) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
     }
-    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    a.canvas_gx = 0;
+    if (V2 && conv_mode() >= 4 && STRIDE == 1 && TH * TW == 256 && canvas_ok(d, TW)) {
+        // small images: tile a canvas of gx images per row with one-pixel gutters instead of every image on its own
+        a.canvas_gx = TW / (d->wout + 1);
+        const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
+        a.tiles_x = 1;
+        a.tiles_y = (rows * (d->hout + 1) + TH - 1) / TH;
+        nblk = (long long)a.tiles_y * a.n_cgroups;  // the kernel's item decode then yields image 0, y0 = canvas row, x0 = 0
+    }
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);
         return AY_ERR_ARG;
@@ -1084,7 +1105,15 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     a.dbg = 0;
     a.stagger = 0;
     a.deal = nullptr;
-    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    a.canvas_gx = 0;
+    if (!CAT && canvas_ok(d, TW)) {
+        a.canvas_gx = TW / (d->wout + 1);
+        const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
+        a.tiles_x = 1;
+        a.tiles_y = (rows * (d->hout + 1) + TH - 1) / TH;
+        nblk = (long long)a.tiles_y * a.n_cgroups;
+    }
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);
         return AY_ERR_ARG;

@@ -29,7 +29,22 @@ struct ConvArgs {
     const uint8_t* src1;  // ring kernel, CAT variant: the first c1 input channels come from this tensor at half resolution
     int c1;               // (nearest x2 upsample folded into the loader); `src` then holds channels c1..cin-1
     unsigned* deal;  // ring kernel: per-launch work counters (8 per-XCD item counters + 1 exit counter), nullptr = static dealing
+    // Small images (13x13, 8x8 grids: the deep layers at the reference's default 416-px input) fill a third of a 8x32 pixel
+    // tile.  canvas_gx > 0: the tile grid lies on a virtual canvas instead -- canvas_gx images side by side, the rest of the batch
+    // below, one zero column / row between neighbours (their shared halo) -- and every tile pixel maps to (image, y, x) or to
+    // nothing.  Stride-1 same-size convolutions only; per-lane image offsets are 32-bit (host-checked).
+    int canvas_gx;
 };
+
+// canvas pixel -> image pixel; false: gutter / beyond the batch (reads as zero, is never stored)
+__device__ __forceinline__ bool canvas_px(const ConvArgs& a, int cy, int cx, int& b, int& y, int& x) {
+    const int H1 = a.hout + 1, W1 = a.wout + 1;
+    const int iy = cy / H1, ix = cx / W1;
+    y = cy - iy * H1;
+    x = cx - ix * W1;
+    b = iy * a.canvas_gx + ix;
+    return cy >= 0 && cx >= 0 && y < a.hout && x < a.wout && ix < a.canvas_gx && b < a.batch;
+}
 
 // ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
 // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -56,14 +71,15 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
             // clamped pixel: an always-valid address, so the loads are unconditional (a load under `if (ok)`, or an address
             // select the compiler turns into a branch, is waited for on the spot and serialises the residual stream);
             // pixels outside the image are never stored
-            const int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1);
+            int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1), bb = b;
+            if (a.canvas_gx && !canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;  // any valid address
             const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
                     const int ch0 = cbase + m * 32 + qp * 16;
-                    const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
+                    const size_t plane = (size_t)bb * (CP / 16) + (ch0 >> 4);
                     rr.r[m][n][qp] = *reinterpret_cast<const uint4*>(a.residual + (plane * out_plane_px + pix) * 32 + hh * 16);
                 }
         }
@@ -136,8 +152,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
-        const int oy = y0 + p / TW, ox = x0 + p % TW;
-        const bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
+        int oy = y0 + p / TW, ox = x0 + p % TW, bn = b;  // bn: the image of this lane's pixel (canvas mode: per lane)
+        bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
+        if (a.canvas_gx) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -177,7 +194,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     w23 = f32x2{q[o + Q1 + 2], q[o + Q1 + 3]} * f32x2{s1[2], s1[3]} + f32x2{t1[2], t1[3]};
                     v01 = leaky2(v01, slope), v23 = leaky2(v23, slope), w01 = leaky2(w01, slope), w23 = leaky2(w23, slope);
                 }
-                const size_t plane = (size_t)b * (CP / 16) + (ch0 >> 4);
+                const size_t plane = (size_t)bn * (CP / 16) + (ch0 >> 4);
                 if constexpr (OUT_F32) {
                     // [plane][pixel][16 f32]: quad 2qp -> elems 4hh.., quad 2qp+1 -> elems 8+4hh..
                     if (ok) {

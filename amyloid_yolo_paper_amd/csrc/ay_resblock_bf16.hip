@@ -373,6 +373,7 @@ extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const 
     a.dbg = 0;
     a.stagger = 0;
     a.deal = nullptr;
+    a.canvas_gx = 0;
     a.src1 = nullptr;
     a.c1 = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;

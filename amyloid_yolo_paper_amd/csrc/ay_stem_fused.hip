@@ -308,6 +308,7 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     a.dbg = 0;
     a.stagger = 0;
     a.deal = nullptr;
+    a.canvas_gx = 0;
     a.src1 = nullptr;
     a.c1 = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;

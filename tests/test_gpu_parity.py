@@ -143,6 +143,12 @@ CONV_CASES = [
     (512, 256, 1, 1, 20, True, False, False),   # 1x1 with the 256-channel tile (BN=256), ragged
     (1024, 512, 1, 1, 13, True, False, False),  # 1x1 BN=256, two channel groups, 13x13
     (256, 256, 1, 1, 32, False, False, False),  # 1x1 BN=256, linear
+    # canvas tiling (several small images per pixel tile, one-pixel gutters): odd batches leave the last canvas row half empty
+    (128, 256, 3, 1, 13, True, True, False, 7),
+    (256, 128, 1, 1, 13, True, False, False, 5),
+    (512, 256, 1, 1, 13, True, False, False, 9),   # BN=256 1x1
+    (64, 64, 3, 1, 5, True, True, False, 11),      # five images across a tile (gx = 5), BN=64
+    (128, 128, 3, 1, 15, True, False, False, 4),   # largest image that still fits twice (2 x 16 = 32 columns)
 ]
 
 
@@ -151,10 +157,10 @@ def test_conv_bf16_kernel(dev, case):
     """bf16 MFMA block vs torch-CPU fp32 conv of the bf16-rounded operands (+affine, leaky, residual), rounded once.
     Tolerance: 1 bf16 ulp of the result (2^-7 relative: a sum that lands next to a rounding boundary may round
     the other way) + 1e-3 absolute for accumulation-order noise."""
-    cin, cout, k, stride, H, leaky, has_res, out_f32 = case
+    cin, cout, k, stride, H, leaky, has_res, out_f32 = case[:8]
     L = _lib.lib()
     st = _lib.stream_ptr()
-    B = 2
+    B = case[8] if len(case) > 8 else 2
     g = torch.Generator().manual_seed(cin * 7 + cout + k + H)
     x = _bf16r(torch.randn(B, cin, H, H, generator=g))
     w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
