@@ -961,13 +961,18 @@ int conv_num_cus() {
     return n;
 }
 
-// canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers whose images fit at least twice across a tile and
+// canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers whose images fit across a tile, save tiles that way and
 // whose tensors stay below 2 GiB (per-lane image offsets are 32-bit); AY_CANVAS=0 turns it off
-static bool canvas_ok(const ay_conv_desc* d, int tw) {
+static bool canvas_ok(const ay_conv_desc* d, int th, int tw) {
     static const int on = getenv("AY_CANVAS") ? atoi(getenv("AY_CANVAS")) : 1;
     const long long px = (long long)d->hout * d->wout;
-    return on && !d->out_f32 && d->hin == d->hout && d->win == d->wout && 2 * (d->wout + 1) <= tw && d->batch > 1 &&
-           px * d->batch * d->cin * 2 < (1ll << 31) && px * d->batch * d->cout_pad * 2 < (1ll << 31);
+    if (!on || d->out_f32 || d->hin != d->hout || d->win != d->wout || d->wout + 1 > tw || d->batch < 2) return false;
+    if (px * d->batch * d->cin * 2 >= (1ll << 31) || px * d->batch * d->cout_pad * 2 >= (1ll << 31)) return false;
+    // worth it when the canvas needs at least a tenth fewer tiles than image-by-image tiling
+    const int gx = tw / (d->wout + 1), rows = (d->batch + gx - 1) / gx;
+    const long long canvas_tiles = ((long long)rows * (d->hout + 1) + th - 1) / th;
+    const long long image_tiles = (long long)d->batch * ((d->hout + th - 1) / th) * ((d->wout + tw - 1) / tw);
+    return canvas_tiles * 10 <= image_tiles * 9;
 }
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
@@ -1013,7 +1018,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     }
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
-    if (V2 && conv_mode() >= 4 && STRIDE == 1 && TH * TW == 256 && canvas_ok(d, TW)) {
+    if (V2 && conv_mode() >= 4 && STRIDE == 1 && canvas_ok(d, TH, TW)) {
         // small images: tile a canvas of gx images per row with one-pixel gutters instead of every image on its own
         a.canvas_gx = TW / (d->wout + 1);
         const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
@@ -1107,7 +1112,7 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     a.deal = nullptr;
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
-    if (!CAT && canvas_ok(d, TW)) {
+    if (!CAT && canvas_ok(d, TH, TW)) {
         a.canvas_gx = TW / (d->wout + 1);
         const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
         a.tiles_x = 1;

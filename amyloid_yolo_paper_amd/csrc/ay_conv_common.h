@@ -112,9 +112,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     // buffer descriptor over image b's output; offsets >= num_records are dropped, so the out-of-image sentinel 0x80000000
     // (+ a plane offset) needs an image below 2 GiB: host check
     const unsigned plane_bytes = (unsigned)out_plane_px * 32u;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.out + (size_t)__builtin_amdgcn_readfirstlane(b) * (CP / 16) * out_plane_px * 32, 0, (int)(plane_bytes * (unsigned)(CP / 16)),
-        0x00020000);
+    const unsigned img_bytes = plane_bytes * (unsigned)(CP / 16);
+    // canvas mode: a lane's image varies, the descriptors span the whole tensor (below 2 GiB there, host-checked) and the image
+    // offset rides in the vector offset
+    const unsigned n_img = a.canvas_gx ? (unsigned)a.batch : 1u;
+    const int b0 = a.canvas_gx ? 0 : __builtin_amdgcn_readfirstlane(b);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b0 * img_bytes, 0, (int)(img_bytes * n_img), 0x00020000);
 
     // residual loaded here (RES_INLINE), RD blocks ahead of its use: vmcnt retires in order, STORES INCLUDED, so a residual load
     // issued behind an output store cannot be waited for before that store has completed.  No store is therefore issued until
@@ -130,14 +133,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     u32x4 outv[DEFER ? NB : 1][2];
     // residual through a buffer descriptor as well: a 32-bit pixel offset per lane + the plane in the scalar offset (no 64-bit
     // address arithmetic in vector registers; this epilogue runs at the register limit)
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(a.residual) + (size_t)__builtin_amdgcn_readfirstlane(b) * (CP / 16) * out_plane_px * 32, 0,
-        (int)(plane_bytes * (unsigned)(CP / 16)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.residual) + (size_t)b0 * img_bytes, 0,
+                                                                           (int)(img_bytes * n_img), 0x00020000);
     auto load_res = [&](int t, uint4 (&r)[2]) __attribute__((always_inline)) {
         const int n = t / MT, m = t % MT;
         const int p = (wn * NT + n) * 32 + c;
-        const int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1);  // clamped: see residual_prefetch
-        const unsigned pix_off = ((unsigned)oy * a.wout + ox) * 32u + hh * 16u;
+        int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1), bb = 0;  // clamped: see residual_prefetch
+        if (a.canvas_gx && !canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;
+        const unsigned pix_off = ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bb * img_bytes;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes);
@@ -236,9 +239,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int p = (wn * NT + n) * 32 + c;
-            const int oy = y0 + p / TW, ox = x0 + p % TW;
-            const bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
-            const unsigned vo = ok ? ((unsigned)oy * a.wout + ox) * 32u + hh * 16u : 0x80000000u;
+            int oy = y0 + p / TW, ox = x0 + p % TW, bn = 0;
+            bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
+            if (a.canvas_gx) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
+            const unsigned vo = ok ? ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -149,6 +149,10 @@ CONV_CASES = [
     (512, 256, 1, 1, 13, True, False, False, 9),   # BN=256 1x1
     (64, 64, 3, 1, 5, True, True, False, 11),      # five images across a tile (gx = 5), BN=64
     (128, 128, 3, 1, 15, True, False, False, 4),   # largest image that still fits twice (2 x 16 = 32 columns)
+    (128, 256, 3, 1, 26, True, True, False, 5),    # one image across, stacked with one-row gutters: 16x32 tile, deferred stores
+    (64, 128, 3, 1, 26, True, False, False, 3),    # the same without residual
+    (256, 128, 1, 1, 26, True, False, False, 5),   # 1x1 on the stacked canvas
+    (128, 256, 3, 1, 31, True, True, False, 3),    # widest image of the canvas mode (32 columns with its gutter)
 ]
 
 
