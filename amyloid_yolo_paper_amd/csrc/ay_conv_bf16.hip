@@ -961,18 +961,28 @@ int conv_num_cus() {
     return n;
 }
 
-// canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers whose images fit across a tile, save tiles that way and
-// whose tensors stay below 2 GiB (per-lane image offsets are 32-bit); AY_CANVAS=0 turns it off
-static bool canvas_ok(const ay_conv_desc* d, int th, int tw) {
+// canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers that save tiles that way and whose tensors stay below
+// 2 GiB (per-lane image offsets are 32-bit); AY_CANVAS=0 turns it off.
+// Returns the number of images per canvas row (0: tile image by image) and the canvas' tile grid.
+static int canvas_plan(const ay_conv_desc* d, int th, int tw, int* tiles_x, int* tiles_y) {
     static const int on = getenv("AY_CANVAS") ? atoi(getenv("AY_CANVAS")) : 1;
     const long long px = (long long)d->hout * d->wout;
-    if (!on || d->out_f32 || d->hin != d->hout || d->win != d->wout || d->wout + 1 > tw || d->batch < 2) return false;
-    if (px * d->batch * d->cin * 2 >= (1ll << 31) || px * d->batch * d->cout_pad * 2 >= (1ll << 31)) return false;
-    // worth it when the canvas needs at least a tenth fewer tiles than image-by-image tiling
-    const int gx = tw / (d->wout + 1), rows = (d->batch + gx - 1) / gx;
-    const long long canvas_tiles = ((long long)rows * (d->hout + 1) + th - 1) / th;
+    if (!on || d->out_f32 || d->hin != d->hout || d->win != d->wout || d->batch < 2) return 0;
+    if (px * d->batch * d->cin * 2 >= (1ll << 31) || px * d->batch * d->cout_pad * 2 >= (1ll << 31)) return 0;
     const long long image_tiles = (long long)d->batch * ((d->hout + th - 1) / th) * ((d->wout + tw - 1) / tw);
-    return canvas_tiles * 10 <= image_tiles * 9;
+    long long best = image_tiles;
+    int best_gx = 0;
+    for (int gx = 1; gx <= d->batch && gx <= 64; ++gx) {  // images per canvas row: the one that needs the fewest tiles
+        const int rows = (d->batch + gx - 1) / gx;
+        const long long tx = ((long long)gx * (d->wout + 1) + tw - 1) / tw, ty = ((long long)rows * (d->hout + 1) + th - 1) / th;
+        if (tx * ty < best) {
+            best = tx * ty;
+            best_gx = gx;
+            *tiles_x = (int)tx;
+            *tiles_y = (int)ty;
+        }
+    }
+    return best * 10 <= image_tiles * 9 ? best_gx : 0;  // worth it from a tenth fewer tiles
 }
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
@@ -1018,13 +1028,14 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     }
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
-    if (V2 && conv_mode() >= 4 && STRIDE == 1 && canvas_ok(d, TH, TW)) {
-        // small images: tile a canvas of gx images per row with one-pixel gutters instead of every image on its own
-        a.canvas_gx = TW / (d->wout + 1);
-        const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
-        a.tiles_x = 1;
-        a.tiles_y = (rows * (d->hout + 1) + TH - 1) / TH;
-        nblk = (long long)a.tiles_y * a.n_cgroups;  // the kernel's item decode then yields image 0, y0 = canvas row, x0 = 0
+    int ctx = 0, cty = 0;
+    if (V2 && conv_mode() >= 4 && STRIDE == 1 && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
+        // images that leave much of their tiles empty: tile a canvas of gx images per row with one-pixel gutters instead
+        a.tiles_x = ctx;
+        a.tiles_y = cty;
+        nblk = (long long)ctx * cty * a.n_cgroups;  // the kernel's item decode then yields image 0 and (y0, x0) on the canvas
+    } else {
+        a.canvas_gx = 0;
     }
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);
@@ -1112,12 +1123,13 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     a.deal = nullptr;
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
-    if (!CAT && canvas_ok(d, TH, TW)) {
-        a.canvas_gx = TW / (d->wout + 1);
-        const int rows = (d->batch + a.canvas_gx - 1) / a.canvas_gx;
-        a.tiles_x = 1;
-        a.tiles_y = (rows * (d->hout + 1) + TH - 1) / TH;
-        nblk = (long long)a.tiles_y * a.n_cgroups;
+    int ctx = 0, cty = 0;
+    if (!CAT && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
+        a.tiles_x = ctx;
+        a.tiles_y = cty;
+        nblk = (long long)ctx * cty * a.n_cgroups;
+    } else {
+        a.canvas_gx = 0;
     }
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("conv grid out of range (%lld)", nblk);

@@ -152,7 +152,10 @@ CONV_CASES = [
     (128, 256, 3, 1, 26, True, True, False, 5),    # one image across, stacked with one-row gutters: 16x32 tile, deferred stores
     (64, 128, 3, 1, 26, True, False, False, 3),    # the same without residual
     (256, 128, 1, 1, 26, True, False, False, 5),   # 1x1 on the stacked canvas
-    (128, 256, 3, 1, 31, True, True, False, 3),    # widest image of the canvas mode (32 columns with its gutter)
+    (128, 256, 3, 1, 31, True, True, False, 3),    # an image as wide as a tile with its gutter
+    (64, 128, 3, 1, 52, True, True, False, 3),     # canvas wider than a tile: three 53-column cells over five tiles
+    (128, 64, 1, 1, 52, True, False, False, 5),
+    (32, 128, 3, 1, 104, True, False, False, 2),
 ]
 
 
