@@ -586,8 +586,9 @@ __device__ unsigned long long g_phase_ticks[8];
 // dynamic item dealing: 64 rotating sets of {8 per-XCD item counters, exit counter}; zero at load, reset by the last workgroup
 __device__ unsigned g_deal[64][16];
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
+    static_assert(!CANVAS || (STRIDE == 1 && !CAT), "canvas tiling: stride-1 single-source layers");
     static_assert(!CAT || (KS == 1 && STRIDE == 1), "route + upsample folding exists for the 1x1 kernel");
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
@@ -722,7 +723,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 int ix = x0 * STRIDE - PAD + P % IN_W;
                 bool inside = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
                 int img = 0;  // canvas mode: this lane's image; its planes lie img * (cin/16) planes further on
-                if (!CAT && a.canvas_gx) inside = canvas_px(a, iy, ix, img, iy, ix);
+                if constexpr (CANVAS) inside = canvas_px(a, iy, ix, img, iy, ix);
                 if (q < NK * PX_PIECES && h < 2 && inside) {
                     off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16 + img * (a.cin / 16) * (int)in_plane;
                     off1 = (int)(kk * in_plane1) + ((iy >> 1) * (a.win >> 1) + (ix >> 1)) * 32 + h * 16;
@@ -848,7 +849,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
-            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES, CANVAS>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
 
             const uint8_t* L = lds + cur * BUF_BYTES;
             constexpr int NSTEP = NK * KK2;
@@ -908,7 +909,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         }
         int fetched = last;
         if (MAILBOX && tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                        reinterpret_cast<const float*>(lds + SS_BASE + par * SSR));
         if (MAILBOX && tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
@@ -1049,7 +1050,12 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             const int cu_slots = conv_num_cus() / 8;
             dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
             constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
-            if (residual)
+            constexpr bool CV = STRIDE == 1;  // the canvas variants exist for the stride-1 kernels
+            if (a.canvas_gx && residual)
+                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, CV>), pgrid, block, 0, st, a, (int)nblk);
+            else if (a.canvas_gx)
+                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, CV>), pgrid, block, 0, st, a, (int)nblk);
+            else if (residual)
                 hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
             else
                 hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
@@ -1139,7 +1145,10 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     const int cu_slots = conv_num_cus() / 8;
     dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     constexpr int NBUF = ring_depth<1, 1, BN, TH, TW, NK>();
-    hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
+    if (a.canvas_gx)
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, false, !CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
+    else
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
     AY_CHECK_LAUNCH("conv_bf16_ring_kernel<1x1>");
     return AY_OK;
 }

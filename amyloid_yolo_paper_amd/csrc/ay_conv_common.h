@@ -58,7 +58,7 @@ struct ResRegs {
     uint4 r[MT][NT][2];
 };
 
-template <int BN, int MT, int NT, int TW, bool HAS_RES>
+template <int BN, int MT, int NT, int TW, bool HAS_RES, bool CANVAS = false>
 __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT, NT>& rr, int b, int cg, int wm, int wn, int c,
                                                   int hh, int y0, int x0) {
     if constexpr (HAS_RES) {
@@ -72,7 +72,9 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
             // select the compiler turns into a branch, is waited for on the spot and serialises the residual stream);
             // pixels outside the image are never stored
             int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1), bb = b;
-            if (a.canvas_gx && !canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;  // any valid address
+            if constexpr (CANVAS) {
+                if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;  // any valid address
+            }
             const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -100,7 +102,9 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 // slope 1 for linear layers, one v_cvt_pk_bf16_f32 per two outputs.  The epilogue is VALU-bound -- with scalar ops, compare +
 // select and one convert per value it cost ~85 VALU instructions per 8 outputs, 4-5 us per 16x32 item with no MFMA running.
 // The IEEE operations and their order are unchanged (no contraction), so are the results, bit for bit.
-template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0>
+// CANVAS: the tile lies on the canvas of ConvArgs::canvas_gx (a compile-time switch: as run-time branches the mapping code
+// cost the kernels that never use it SGPR spills -- the fused block went from 1.36 to 1.81 ms)
+template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0, bool CANVAS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
                                               int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr) {
     const int CP = a.cout_pad;
@@ -115,8 +119,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     const unsigned img_bytes = plane_bytes * (unsigned)(CP / 16);
     // canvas mode: a lane's image varies, the descriptors span the whole tensor (below 2 GiB there, host-checked) and the image
     // offset rides in the vector offset
-    const unsigned n_img = a.canvas_gx ? (unsigned)a.batch : 1u;
-    const int b0 = a.canvas_gx ? 0 : __builtin_amdgcn_readfirstlane(b);
+    const unsigned n_img = CANVAS ? (unsigned)a.batch : 1u;
+    const int b0 = CANVAS ? 0 : __builtin_amdgcn_readfirstlane(b);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b0 * img_bytes, 0, (int)(img_bytes * n_img), 0x00020000);
 
     // residual loaded here (RES_INLINE), RD blocks ahead of its use: vmcnt retires in order, STORES INCLUDED, so a residual load
@@ -139,7 +143,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         const int n = t / MT, m = t % MT;
         const int p = (wn * NT + n) * 32 + c;
         int oy = min(y0 + p / TW, a.hout - 1), ox = min(x0 + p % TW, a.wout - 1), bb = 0;  // clamped: see residual_prefetch
-        if (a.canvas_gx && !canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;
+        if constexpr (CANVAS) {
+            if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;
+        }
         const unsigned pix_off = ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bb * img_bytes;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
@@ -157,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         const int p = (wn * NT + n) * 32 + c;
         int oy = y0 + p / TW, ox = x0 + p % TW, bn = b;  // bn: the image of this lane's pixel (canvas mode: per lane)
         bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
-        if (a.canvas_gx) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
+        if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
         const size_t pix = (size_t)oy * a.wout + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             const int p = (wn * NT + n) * 32 + c;
             int oy = y0 + p / TW, ox = x0 + p % TW, bn = 0;
             bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
-            if (a.canvas_gx) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
+            if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
             const unsigned vo = ok ? ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
