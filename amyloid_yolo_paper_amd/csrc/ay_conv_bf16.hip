@@ -588,7 +588,7 @@ __device__ unsigned g_deal[64][16];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
-    static_assert(!CANVAS || (STRIDE == 1 && !CAT), "canvas tiling: stride-1 single-source layers");
+    static_assert(!CANVAS || !CAT, "canvas tiling: single-source layers");
     static_assert(!CAT || (KS == 1 && STRIDE == 1), "route + upsample folding exists for the 1x1 kernel");
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 int ix = x0 * STRIDE - PAD + P % IN_W;
                 bool inside = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
                 int img = 0;  // canvas mode: this lane's image; its planes lie img * (cin/16) planes further on
-                if constexpr (CANVAS) inside = canvas_px(a, iy, ix, img, iy, ix);
+                if constexpr (CANVAS) inside = canvas_px_in<STRIDE>(a, iy, ix, img, iy, ix);
                 if (q < NK * PX_PIECES && h < 2 && inside) {
                     off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16 + img * (a.cin / 16) * (int)in_plane;
                     off1 = (int)(kk * in_plane1) + ((iy >> 1) * (a.win >> 1) + (ix >> 1)) * 32 + h * 16;
@@ -968,8 +968,9 @@ int conv_num_cus() {
 static int canvas_plan(const ay_conv_desc* d, int th, int tw, int* tiles_x, int* tiles_y) {
     static const int on = getenv("AY_CANVAS") ? atoi(getenv("AY_CANVAS")) : 1;
     const long long px = (long long)d->hout * d->wout;
-    if (!on || d->out_f32 || d->hin != d->hout || d->win != d->wout || d->batch < 2) return 0;
-    if (px * d->batch * d->cin * 2 >= (1ll << 31) || px * d->batch * d->cout_pad * 2 >= (1ll << 31)) return 0;
+    if (!on || d->out_f32 || d->batch < 2) return 0;
+    if (d->stride == 1 ? (d->hin != d->hout || d->win != d->wout) : (d->hin != 2 * d->hout || d->win != 2 * d->wout)) return 0;
+    if ((long long)d->hin * d->win * d->batch * d->cin * 2 >= (1ll << 31) || px * d->batch * d->cout_pad * 2 >= (1ll << 31)) return 0;
     const long long image_tiles = (long long)d->batch * ((d->hout + th - 1) / th) * ((d->wout + tw - 1) / tw);
     long long best = image_tiles;
     int best_gx = 0;
@@ -1030,7 +1031,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
     int ctx = 0, cty = 0;
-    if (V2 && conv_mode() >= 4 && STRIDE == 1 && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
+    if (V2 && conv_mode() >= 4 && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
         // images that leave much of their tiles empty: tile a canvas of gx images per row with one-pixel gutters instead
         a.tiles_x = ctx;
         a.tiles_y = cty;
@@ -1050,7 +1051,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
             const int cu_slots = conv_num_cus() / 8;
             dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
             constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
-            constexpr bool CV = STRIDE == 1;  // the canvas variants exist for the stride-1 kernels
+            constexpr bool CV = true;
             if (a.canvas_gx && residual)
                 hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, CV>), pgrid, block, 0, st, a, (int)nblk);
             else if (a.canvas_gx)

@@ -45,6 +45,21 @@ __device__ __forceinline__ bool canvas_px(const ConvArgs& a, int cy, int cx, int
     b = iy * a.canvas_gx + ix;
     return cy >= 0 && cx >= 0 && y < a.hout && x < a.wout && ix < a.canvas_gx && b < a.batch;
 }
+// the INPUT canvas of a stride-S layer: cells S times as large (input pixel S*y - pad + tap of output pixel y stays inside its own
+// cell or falls into the gutter, where it reads as the zero padding)
+template <int S>
+__device__ __forceinline__ bool canvas_px_in(const ConvArgs& a, int cy, int cx, int& b, int& y, int& x) {
+    if constexpr (S == 1) {
+        return canvas_px(a, cy, cx, b, y, x);
+    } else {
+        const int H1 = S * (a.hout + 1), W1 = S * (a.wout + 1);
+        const int iy = cy / H1, ix = cx / W1;
+        y = cy - iy * H1;
+        x = cx - ix * W1;
+        b = iy * a.canvas_gx + ix;
+        return cy >= 0 && cx >= 0 && y < a.hin && x < a.win && ix < a.canvas_gx && b < a.batch;
+    }
+}
 
 // ---- epilogue: affine + leaky (+ residual) -> direct stores -------------------------------------------
 // C/D layout of 32x32: col (pixel) = lane&31, row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).

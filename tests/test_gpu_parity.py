@@ -156,6 +156,9 @@ CONV_CASES = [
     (64, 128, 3, 1, 52, True, True, False, 3),     # canvas wider than a tile: three 53-column cells over five tiles
     (128, 64, 1, 1, 52, True, False, False, 5),
     (32, 128, 3, 1, 104, True, False, False, 2),
+    (128, 256, 3, 2, 26, True, False, False, 5),   # stride 2 on the canvas: 13x13 outputs, input cells twice as large
+    (64, 128, 3, 2, 52, True, False, False, 3),    # BN=128, 26x26 outputs
+    (32, 64, 3, 2, 16, True, False, False, 9),     # BN=64, 8x8 outputs
 ]
 
 
