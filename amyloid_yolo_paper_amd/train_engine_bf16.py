@@ -275,6 +275,8 @@ def train_backward_bf16(model, stt, grad_scale=1.0):
             check(L.ay_bn_train_bwd_bf16(ptr(dy), ptr(rec["z"]), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(rec["mean"]), ptr(rec["invstd"]),
                                          int(e["leaky"]), ptr(dz), ptr(dg), ptr(db), ptr(rec["keep"][1]), B, cout, hout, hout, st), "ay_bn_train_bwd_bf16")
             grads[bn.weight], grads[bn.bias] = dg, db
+        if getattr(model, "_dbg_keep_dz", None) is not None and i in model._dbg_keep_dz:
+            model._dbg_keep_dz[i] = dz
         # ---- weight gradient (matrix cores, K = pixels)
         if rec.get("stem"):
             d_w = ConvDesc(B, cin, cout, hin, hin, hout, hout, k, e["stride"], 0, 0, rec["cpad"])  # cin = 3: rows ci >= 3 of the plane are skipped

@@ -1,0 +1,65 @@
+"""BASELINE.json configurations at their full shape on the GPU (-m gpu).
+
+configs[1]: bf16 MFMA path, batch 64 of 1024x1024 tiles, decode + merge-NMS -- the configuration bench.py times -- against the
+reference's own output for the 1024^2 fixture tile (tests/golden/model_c3_s1024_b1.npz, produced by oracle/gen_golden.py
+from the imported reference: models.py:237-255 + utils/utils.py:235-273)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from amyloid_yolo_paper_amd import utils as ay
+from oracle import parity
+from test_gpu_parity import build_models, load
+
+pytestmark = pytest.mark.gpu
+
+# Bars for the bf16 product path against the reference's fp32 CPU result.  north_star asks for bit-exact indices and 1e-4
+# boxes "on identical tiles"; the fp32 HIP path meets exactly that (test_model_fp32_vs_reference_fixtures, 1024^2 included).  A
+# path that stores every activation in bf16 cannot: a confidence within bf16 noise (~0.02) of the 0.5 threshold enters or
+# leaves the candidate set, and the synthetic heads are calibrated so that the threshold sits in the bulk of the
+# distribution (on the fixture tile 521 of 64 512 rows lie within 0.02 of it, against 445 candidates).  What the rounding
+# CONTRACT itself attains was measured with the CPU oracle in mode="bf16" on this tile (exact same rounding points, fp32 and
+# float64 convolution sums): 0.817 / 0.835 of the reference's 230 kept indices, 0.126 / 0.090 extra heads, confidences of
+# matched heads within 0.023, boxes of matched heads within 0.33 of the box size (a head whose cluster gained or lost a
+# member moves with the conf-weighted merge, utils/utils.py:259-269).  The HIP path is held to the contract's own level:
+KEEP_MATCH_MIN = 0.78      # fraction of the reference's kept box indices (cluster heads) that the bf16 path keeps too
+EXTRA_HEADS_MAX = 0.16     # fraction of the bf16 path's heads that the reference does not have
+BOX_REL_MAX = 0.40         # matched heads: max corner difference relative to the box size (merge membership may differ)
+DCONF_MAX = 0.03           # matched heads: max |confidence difference|
+
+
+def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir):
+    dev = torch.device("cuda", 0)
+    name, C_, S, B1, start = [c for c in gc.MODEL_CASES if c[0] == "c3_s1024_b1"][0]
+    z = load(golden_dir, "model_" + name)
+    m, _ = build_models(C_, tmp_cfg_dir, dev, "bf16")
+    assert m.use_plan and not m.keep_layer_outputs
+    x1 = torch.from_numpy(gc.model_inputs(S, B1, start))            # the fixture's tile
+    out1 = m.forward_device(x1).clone()
+    assert bool(torch.isfinite(out1).all())
+    # the same tile 64 times through the native plan (ay_plan_forward) at the benchmark shape: the 2 GiB descriptor guard, 64
+    # rotating deal-counter sets over ~76 launches and the arena's lifetime reuse all act at this size
+    B = 64
+    x64 = x1.to(dev).repeat(B, 1, 1, 1).contiguous()
+    for rep in range(2):                                             # twice: the second pass reuses arena and counter sets
+        out64 = m.forward_device(x64)
+        assert out64.shape == (B, m.num_boxes(S), 5 + C_)
+        assert bool(torch.isfinite(out64).all()), "non-finite rows"
+        same = (out64 == out1[0:1]).all(dim=2).all(dim=1)
+        assert bool(same.all()), f"pass {rep}: copies {torch.nonzero(~same).flatten().tolist()} differ from the batch-1 result"
+    res = ay.non_max_suppression(out64.clone(), 0.5, 0.4)
+    for b in range(1, B):
+        assert np.array_equal(res.keep_idx[b], res.keep_idx[0]) and torch.equal(res[b], res[0])
+    agree = parity.detection_agreement(z["nms_keep0"], z["nms_rows0"], res.keep_idx[0], res[0].cpu().numpy())
+    s = parity.summarize([agree])
+    print("configs[1] bf16 vs reference fixture:", s)
+    assert s["keep_match"] >= KEEP_MATCH_MIN and s["extra_heads"] <= EXTRA_HEADS_MAX, s
+    assert s["max_box_rel"] <= BOX_REL_MAX and s["max_dconf"] <= DCONF_MAX and agree["cls_equal"], s
+    # decoded rows of the fixture's sample: confidences / classes within bf16 noise, boxes relative to their size
+    got = out1[0].cpu().numpy()[z["out_rows"]]
+    ref = z["out_sel"][0]
+    dconf = np.abs(got[:, 4:] - ref[:, 4:])
+    rel = np.abs(got[:, :4] - ref[:, :4]) / np.maximum(1.0, ref[:, 2:4].max(-1, keepdims=True))
+    print("decoded sample: dconf q99 %.4f max %.4f, box rel q99.9 %.4f" % (np.quantile(dconf, 0.99), dconf.max(), np.quantile(rel, 0.999)))
+    assert np.quantile(dconf, 0.99) <= 2e-2 and np.quantile(rel, 0.999) <= 5e-2

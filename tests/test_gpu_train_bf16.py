@@ -155,21 +155,75 @@ def test_bn_train_bf16_fwd_bwd_and_plumbing():
     assert torch.equal(from_blocked(d2, 32), bf(dout[:, 16:] + 1.0))
 
 
-def test_bf16_train_step_tracks_fp32_step(tmp_cfg_dir):
-    """One training step on the bf16 MFMA path vs the fp32 reference-precision path (same model, weights, batch).
+def _downstream_convs(defs):
+    """per convolutional layer: the largest number of convolutions between it and a detection head (0 for the heads); the
+    gradient is a sum over paths, each stored gradient tensor on a path is rounded once (2 per convolution layer), and the
+    relative error of the sum is at most that of its longest path."""
+    n = len(defs)
+    users = {i: [] for i in range(n)}
+    for i, d in enumerate(defs):
+        t = d["type"]
+        if t == "route":
+            srcs = [int(j) for j in d["layers"].split(",")]
+            for j in srcs:
+                users[j if j >= 0 else i + j].append(i)
+        elif t == "shortcut":
+            users[i - 1].append(i)
+            j = int(d["from"])
+            users[j if j >= 0 else i + j].append(i)
+        elif i > 0:
+            users[i - 1].append(i)
+    depth = {}
 
-    Every kernel of the bf16 path is pinned against autograd above; end to end the two paths cannot agree tightly below a
-    LeakyReLU: bf16 activations (relative noise 2^-9) put ~0.5-1 % of the pre-activations of every layer on the other
-    side of zero, where the slope differs 10x, so the gradients are evaluated at slightly different points of a
-    piecewise-linear function and decorrelate by ~0.3 % cosine per layer on the way down (measured: 0.9997 at the heads,
-    0.98-0.99 one block below, ~0.67 at layer 0 after 75 layers; scripts/dbg_train_bf16.py prints the whole profile).
-    Checked here: loss within 10 %, heads >= 0.995, the block under each head >= 0.92, everything else >= 0.35 and finite,
-    BN statistics close, and 8 Adam steps on a fixed batch reduce the loss on both paths to within 25 % of each other."""
+    def walk(i):
+        if i in depth:
+            return depth[i]
+        d = defs[i]
+        if d["type"] == "yolo":
+            depth[i] = -1
+            return -1
+        best = max((walk(u) for u in users[i]), default=-1)
+        depth[i] = best + (1 if d["type"] == "convolutional" else 0)
+        return depth[i]
+
+    return {i: walk(i) for i, d in enumerate(defs) if d["type"] == "convolutional"}
+
+
+def test_bf16_train_step_vs_oracle(tmp_cfg_dir):
+    """One training step on the bf16 MFMA path against the CPU oracle (reference: train.py:113-119, models.py:174-222,237-255),
+    teacher-forced: ``OracleDarknet.forward(mode="bf16_train", forced=...)`` evaluates every layer on the activations the HIP
+    step stored (raw convolution outputs z, layer outputs y, fp32 heads), checks its own result against the stored one, and
+    runs fp32 autograd at exactly that forward point -- same LeakyReLU masks, same batch statistics.
+
+    Forward, per layer on identical inputs: same rounding contract, so the stored value may differ from the oracle's by
+    one bf16 ulp where the fp32 sum lands next to a rounding boundary (probability ~ fp32 noise / ulp ~ 1e-3) and by nothing
+    else: no element further than one ulp (1e-4 of them allowed: near-zero values), relative L2 <= 2^-8 * sqrt(4e-3) = 2.5e-4.
+    Backward: what the HIP step adds to the oracle's fp32 gradients is one bf16 rounding (relative error <= u = 2^-8) per
+    stored activation gradient -- two per convolution layer on the way down (dgrad output, BN-backward output) plus the head
+    gradient -- so with L = the largest number of convolutions between a layer and a head the relative L2 error of a weight
+    gradient is bounded by  u * sqrt(2L + 1)  (independent errors of at most u each, in quadrature; measured 4e-4 at the
+    heads to 1.6e-2 at layer 1, about a third of the bound everywhere); per-channel BN / bias gradients (sums of largely
+    cancelling terms over all pixels) get 4x that.  The stem's weight gradient sum(dz * x) is special: the image values share
+    a large mean (tiles lie in [0.7, 1]) that the exact dz nearly cancels (a BatchNorm backward's output sums to zero per
+    channel), whereas the rounding errors of dz do not cancel, so they weigh A = rms(x) / std(x) more (8.7 on these tiles;
+    measured 22 % against 1.4 % on dz itself -- inherent to bf16 gradients on an un-normalised input, an fp32 dz at layer 0
+    alone would not change it because the 1.4 % are inherited from the 70 layers above; centring the image operand is not
+    an option either: the zero padding makes the border terms c * sum(dz) a real part of the off-centre taps' gradient).
+    Its bound is A times the common one.
+    Loss (fp32 loss kernel on forced heads) 1e-4; BN running statistics (PyTorch momentum semantics) 1e-4.
+
+    Why teacher-forced: a bf16 forward is chaotic at the one-ulp level (oracle/darknet_oracle.py docstring) and the gradients
+    of this LeakyReLU network are far more so -- two exact CPU evaluations of the same contract (fp32 vs fp64 convolution
+    sums) differ by 2-4 % in the head gradients, 9-19 % one block below and 50-70 % in the backbone.  Round 1 compared the
+    bf16 with the fp32 path over 8 Adam steps instead; that test was red in GPUTEST_r01.json: Adam's first step is
+    lr * sign(g), the 1e-7 run-to-run noise of the split-K weight-gradient atomics decides the sign of near-zero gradients,
+    and the loss after 8 steps moved +-20 % between runs of one build (150, 156, 193, 204; scripts/dbg/train_determinism.py).
+    The first step itself is reproducible (loss bit-identical, gradients to 2e-6) and independent of canvas tiling
+    (AY_CANVAS=0/1: identical loss, head gradients equal to 4e-8)."""
     import os
-    import sys
-    sys.path.insert(0, os.path.dirname(__file__))
     from amyloid_yolo_paper_amd import cfg_gen, parse_config, synth
     from amyloid_yolo_paper_amd.models import Darknet
+    from oracle.darknet_oracle import OracleDarknet
     C_, S, B = 3, 256, 4
     cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
     defs = parse_config.parse_model_config(cfg)
@@ -178,45 +232,80 @@ def test_bf16_train_step_tracks_fp32_step(tmp_cfg_dir):
         synth.write_darknet_weights(wpath, defs, synth.synth_params(defs, seed=7), seen=0)
     x = torch.from_numpy(synth.synth_tiles(B, S, 10))
     tg = torch.from_numpy(synth.synth_targets(B, C_, seed=21, max_per_tile=6, min_per_tile=3, wh_range=(0.05, 0.4), grid=S // 8))
-    res = {}
-    for prec in ("fp32", "bf16"):
-        m = Darknet(cfg, precision=prec).to("cuda")
-        m.load_darknet_weights(wpath)
-        m.train()
-        loss, out = m(x, tg)
+
+    # ---- HIP step; the activations it stored
+    m = Darknet(cfg, precision="bf16").to("cuda")
+    m.load_darknet_weights(wpath)
+    m.train()
+    loss, out = m(x, tg)
+    stt = loss.grad_fn.stt
+    graph = m._graph
+    forced = {"z": {}, "y": {}}
+    for i, rec in stt.conv.items():
+        if rec["kind"] == "bn":
+            forced["z"][i] = from_blocked(rec["z"], graph[i]["cout"])
+    for i, v in stt.val.items():
+        if v is None or isinstance(v, tuple) or graph[i]["type"] not in ("convolutional", "shortcut"):
+            continue
+        forced["y"][i] = v.float().cpu() if v.dim() == 4 else from_blocked(v, graph[i]["channels"])
+    loss.backward()
+    l16 = float(loss.item())
+
+    # ---- oracle at the same forward point
+    o = OracleDarknet(cfg)
+    o.load_darknet_weights(wpath)
+    o.require_grad()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    lo, _ = o.forward(x, tg, mode="bf16_train", train_bn=True, forced=forced)
+    lo.backward()
+    assert abs(l16 - float(lo.detach())) <= 1e-4 * abs(float(lo.detach())), (l16, float(lo.detach()))
+    n_checked = 0
+    for (kind, i), (frac, rel) in sorted(o.forced_err.items(), key=lambda kv: kv[0][1]):
+        head = kind == "y" and not graph[i].get("bn", True)
+        if head:
+            assert rel <= 1e-5, ("head", i, rel)
+        else:
+            assert frac <= 1e-4 and rel <= 2.5e-4, (kind, i, frac, rel)
+        n_checked += 1
+    assert n_checked >= 72 + 72 - 23 + 3        # z of every BN layer, y of every unfused conv and every shortcut, 3 heads
+
+    depth = _downstream_convs(defs[1:])
+    u = 2.0 ** -8
+    worst = {}
+    names = {"weight": "conv_{i}.weight", "bias": "conv_{i}.bias", "gamma": "batch_norm_{i}.weight", "beta": "batch_norm_{i}.bias"}
+    sd = dict(m.named_parameters())
+    for i, p in o.params.items():
+        bound = u * (2 * depth[i] + 1) ** 0.5
+        if i == 0:
+            bound *= float(x.pow(2).mean().sqrt() / x.std())   # A = rms(x) / std(x), see docstring
+        for k, pat in names.items():
+            if k not in p:
+                continue
+            ref = p[k].grad
+            got = sd[f"module_list.{i}." + pat.format(i=i)].grad.detach().float().cpu()
+            assert torch.isfinite(got).all(), (i, k)
+            rel = float((got - ref).norm() / (ref.norm() + 1e-30))
+            b_ = bound if k == "weight" else 4 * bound
+            worst[(i, k)] = rel / b_
+            if k == "weight" and i in (0, 1, 43, 80, 81, 104, 105):
+                print(f"layer {i:3d} L={depth[i]:2d} dW relL2 {rel:.4f} bound {b_:.4f}")
+    wk = max(worst, key=worst.get)
+    print("worst gradient error / bound:", worst[wk], wk)
+    assert worst[wk] <= 1.0, (wk, worst[wk])
+    for i in (0, 1, 44, 80, 104):
+        bn = m.module_list[i][1]
+        for got, ref in ((bn.running_mean, o.params[i]["mean"]), (bn.running_var, o.params[i]["var"])):
+            ref = ref.detach()
+            assert float((got.detach().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6, i
+
+    # property (not a comparison): 8 Adam steps on the fixed batch reduce the loss
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.step()
+    opt.zero_grad()
+    for _ in range(7):
+        loss, _ = m(x, tg)
         loss.backward()
-        grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
-        stats = {n: b.detach().float().cpu() for n, b in m.named_buffers() if "running" in n}
-        first = float(loss.item())
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
         opt.step()
         opt.zero_grad()
-        for _ in range(7):
-            loss, _ = m(x, tg)
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
-        res[prec] = (first, grads, stats, out, float(loss.item()))
-    l32, g32, s32, o32, e32 = res["fp32"]
-    l16, g16, s16, o16, e16 = res["bf16"]
-    assert abs(l16 - l32) <= 0.10 * abs(l32), (l16, l32)
-    assert e32 < l32 and e16 < l16 and abs(e16 - e32) <= 0.25 * abs(e32), (l32, e32, l16, e16)   # both learn, alike
-
-    def cos(n):
-        a, b_ = g16[n].reshape(-1), g32[n].reshape(-1)
-        assert torch.isfinite(a).all(), n
-        return float(torch.dot(a, b_) / (a.norm() * b_.norm() + 1e-30))
-
-    for n in ("module_list.105.conv_105.weight", "module_list.93.conv_93.weight", "module_list.81.conv_81.weight"):
-        assert cos(n) >= 0.995, (n, cos(n))
-    for n in ("module_list.104.conv_104.weight", "module_list.92.conv_92.weight", "module_list.80.conv_80.weight"):
-        assert cos(n) >= 0.92, (n, cos(n))
-    for n in g32:
-        if ".conv_" in n and n.endswith("weight"):
-            assert cos(n) >= 0.35, (n, cos(n))
-        else:   # BN / bias gradients are heavily cancelling sums (noise dominated in the early layers): finite is all we ask
-            assert torch.isfinite(g16[n]).all(), n
-    for n in ("module_list.1.batch_norm_1.running_mean", "module_list.80.batch_norm_80.running_var"):
-        assert float((s16[n] - s32[n]).abs().max()) <= 0.10 * float(s32[n].abs().max()) + 1e-3, n
-    d = np.abs(o16.numpy()[..., 4:] - o32.numpy()[..., 4:])
-    assert np.quantile(d, 0.95) <= 0.1, float(np.quantile(d, 0.95))   # sigmoid outputs of gain-amplified logits: bulk agreement only
+    e16 = float(loss.item())
+    assert np.isfinite(e16) and e16 < 0.75 * l16, (l16, e16)
