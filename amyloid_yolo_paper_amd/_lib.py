@@ -42,6 +42,7 @@ _SIGS = {
     "ay_stem_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_stem_s2_fused_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "ay_conv_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ay_conv3x3_m16_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ay_concat_upsample_bf16": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _I, _P]),
     "ay_blocked_bf16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_blocked_f32_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -71,6 +71,17 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
                  : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                  : "memory");
 }
+// The same through a buffer descriptor (buffer_load_dwordx4 ... lds): lane l copies 16 B from descriptor base + `soff` (scalar)
+// + `voff` (its own 32-bit offset) to LDS byte address `lds_addr + 16*l`.  A lane whose `voff` is >= the descriptor's
+// num_records (e.g. 0x80000000) is out of range and delivers zeros: border / padding lanes need no zero page and no select,
+// and no lane carries a 64-bit address.  The scalar offset takes no part in the range check.
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                 : "memory");
+}
 // 4-byte variant (global_load_lds_dword): lane l copies 4 B from its own `gsrc` to LDS byte address `lds_addr + 4*l`;
 // for sources that are only 4-byte aligned (fp32 image rows at arbitrary column offsets).
 __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_addr) {

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "ay_conv_common.h"
 
@@ -185,394 +186,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// V2: 8 waves (512 threads), one workgroup per CU, two LDS stage buffers.
-//   * filters go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write); the LDS image
-//     [tap][half][BN][16 B] is exactly the lane-linear order the DMA writes;
-//   * the input halo tile goes through registers (border pixels need zero fill) and is written into the other
-//     buffer after the MFMAs of the current stage;
-//   * one barrier per 16-channel stage; the DMA of stage s+1 is in flight during the MFMAs of stage s.
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2) conv_bf16_dma_kernel(ConvArgs a) {
-    constexpr int NTHR = 512;
-    constexpr int PAD = (KS - 1) / 2;
-    constexpr int KK2 = KS * KS;
-    constexpr int NPIX = TH * TW;
-    constexpr int NT = NPIX / (WN * 32);
-    constexpr int MT = BN / (WM * 32);
-    constexpr int IN_H = (TH - 1) * STRIDE + KS;
-    constexpr int IN_W = (TW - 1) * STRIDE + KS;
-    constexpr int IN_PIX = IN_H * IN_W;
-    constexpr int PIX_SLAB = 2 * IN_PIX * 16;
-    constexpr int W_SLAB = KK2 * 2 * BN * 16;
-    constexpr int W_BASE = NK * PIX_SLAB;
-    constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
-    constexpr int PXU_TOTAL = NK * 2 * IN_PIX;
-    constexpr int NPXU = (PXU_TOTAL + NTHR - 1) / NTHR;
-    constexpr int WU_TOTAL = NK * KK2 * 2 * BN;
-    constexpr int NWU = (WU_TOTAL + NTHR - 1) / NTHR;
-    static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
-    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
-    static_assert(WU_TOTAL % 64 == 0, "filter DMA pieces are whole waves");
-    static_assert(2 * BUF_BYTES <= 160 * 1024, "two stage buffers per CU");
-
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int c = lane & 31, hh = lane >> 5;
-
-    const int bid = blockIdx.x;
-    const int cg = bid % a.n_cgroups;
-    const int pt = bid / a.n_cgroups;
-    const int tile_x = pt % a.tiles_x;
-    const int tile_y = (pt / a.tiles_x) % a.tiles_y;
-    const int b = pt / (a.tiles_x * a.tiles_y);
-    const int y0 = tile_y * TH, x0 = tile_x * TW;
-
-    const size_t in_plane = (size_t)a.hin * a.win * 32;
-    const uint8_t* src_img = a.src + (size_t)b * (a.cin / 16) * in_plane;
-    const int CP = a.cout_pad;
-    const uint8_t* wbase = a.w + (size_t)cg * BN * 16;
-    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
-
-    int px_off[NPXU];
-#pragma unroll
-    for (int i = 0; i < NPXU; ++i) {
-        const int u = i * NTHR + tid;
-        int off = -1;
-        if (u < PXU_TOTAL) {
-            const int kk = u / (2 * IN_PIX);
-            const int v = u % (2 * IN_PIX);
-            const int P = v >> 1, h = v & 1;
-            const int iy = y0 * STRIDE - PAD + P / IN_W;
-            const int ix = x0 * STRIDE - PAD + P % IN_W;
-            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-                off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
-        }
-        px_off[i] = off;
-    }
-    // per-lane source offset of filter DMA piece i inside one stage (piece = 64 lanes x 16 B = 1 KiB of the LDS image)
-    int w_off[NWU];
-#pragma unroll
-    for (int i = 0; i < NWU; ++i) {
-        const int u = i * NTHR + tid;
-        const int r = u % BN, th = u / BN;
-        w_off[i] = (th * CP + r) * 16;
-    }
-
-    uint4 rpx[NPXU];
-
-    auto dma_filters = [&](int s, int buf) {
-        const uint8_t* wp = wbase + (size_t)s * w_stage_stride;
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            if (i * NTHR + wave * 64 < WU_TOTAL) {  // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + w_off[i]),
-                                                 (__attribute__((address_space(3))) void*)(lds + buf * BUF_BYTES + W_BASE +
-                                                                                           (i * NTHR + wave * 64) * 16),
-                                                 16, 0, 0);
-            }
-        }
-    };
-    auto load_pixels = [&](int s) {
-        const uint8_t* sp = src_img + (size_t)s * NK * in_plane;
-#pragma unroll
-        for (int i = 0; i < NPXU; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (px_off[i] >= 0) v = *reinterpret_cast<const uint4*>(sp + px_off[i]);
-            rpx[i] = v;
-        }
-    };
-    auto store_pixels = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NPXU; ++i) {
-            const int u = i * NTHR + tid;
-            if (u < PXU_TOTAL) {
-                const int kk = u / (2 * IN_PIX);
-                const int v = u % (2 * IN_PIX);
-                const int P = v >> 1, h = v & 1;
-                *reinterpret_cast<uint4*>(lds + buf * BUF_BYTES + kk * PIX_SLAB + (h * IN_PIX + P) * 16) = rpx[i];
-            }
-        }
-    };
-
-    int pb[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int p = (wn * NT + n) * 32 + c;
-        const int ty = p / TW, tx = p % TW;
-        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
-    }
-    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    const int nstages = a.cin / (16 * NK);
-    dma_filters(0, 0);
-    load_pixels(0);
-    store_pixels(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-        const int cur = s & 1;
-        const bool more = (s + 1 < nstages);
-        if (more) {
-            load_pixels(s + 1);
-            dma_filters(s + 1, cur ^ 1);
-        }
-        const uint8_t* L = lds + cur * BUF_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-#pragma unroll
-            for (int tap = 0; tap < KK2; ++tap) {
-                const int kh = tap / KS, kw = tap % KS;
-                bf16x8 af[MT], bfr[NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    af[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    bfr[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-            }
-        }
-        if (more) {
-            store_pixels(cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter DMA of stage s+1 has landed
-            __syncthreads();
-        }
-    }
-    ResRegs<MT, NT> rr;
-    residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
-    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// V3: V2's stage pipeline made persistent.  One workgroup per CU walks a list of (pixel tile, channel group)
-// items; the stage pipeline runs straight across item boundaries (the first stage of the next item is loaded
-// during the last stage of the current one), the residual operand is prefetched during the last stage, and
-// the epilogue's stores drain while the next item computes.  Items are dealt so that the workgroups that share
-// an XCD (blockIdx % 8, observed round-robin placement: speed only) walk one contiguous range of items, channel
-// groups of a pixel tile adjacent, so its input halo and the filters stay in that XCD's L2.
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2) conv_bf16_persist_kernel(ConvArgs a, int n_items) {
-    constexpr int NTHR = 512;
-    constexpr int PAD = (KS - 1) / 2;
-    constexpr int KK2 = KS * KS;
-    constexpr int NPIX = TH * TW;
-    constexpr int NT = NPIX / (WN * 32);
-    constexpr int MT = BN / (WM * 32);
-    constexpr int IN_H = (TH - 1) * STRIDE + KS;
-    constexpr int IN_W = (TW - 1) * STRIDE + KS;
-    constexpr int IN_PIX = IN_H * IN_W;
-    constexpr int PIX_SLAB = 2 * IN_PIX * 16;
-    constexpr int W_SLAB = KK2 * 2 * BN * 16;
-    constexpr int W_BASE = NK * PIX_SLAB;
-    constexpr int BUF_BYTES = NK * (PIX_SLAB + W_SLAB);
-    constexpr int PXU_TOTAL = NK * 2 * IN_PIX;
-    constexpr int NPXU = (PXU_TOTAL + NTHR - 1) / NTHR;
-    constexpr int WU_TOTAL = NK * KK2 * 2 * BN;
-    constexpr int NWU = (WU_TOTAL + NTHR - 1) / NTHR;
-    static_assert(WM * WN == 8 && NT >= 1 && MT >= 1, "8 waves");
-    static_assert(NT * WN * 32 == NPIX && MT * WM * 32 == BN, "tile split");
-    static_assert(WU_TOTAL % 64 == 0, "filter DMA pieces are whole waves");
-    static_assert(2 * BUF_BYTES <= 160 * 1024, "two stage buffers per CU");
-
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int c = lane & 31, hh = lane >> 5;
-
-    // ---- item list of this workgroup -----------------------------------------------------------------
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int per_xcd = (n_items + 7) >> 3;
-    const int first = xcd * per_xcd;
-    const int last = min(first + per_xcd, n_items);
-    int item = first + slot;
-    if (item >= last) return;
-
-    const size_t in_plane = (size_t)a.hin * a.win * 32;
-    const int CP = a.cout_pad;
-    const size_t w_stage_stride = (size_t)NK * KK2 * 2 * CP * 16;
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-
-    // loader state (runs one stage ahead of the MFMAs, possibly already in the next item)
-    int px_off[NPXU];
-    const uint8_t* ld_src;
-    const uint8_t* ld_w;
-    auto setup_loader = [&](int it) {
-        const int cg = it % a.n_cgroups;
-        const int pt = it / a.n_cgroups;
-        const int b = pt / tiles_per_img;
-        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
-        ld_src = a.src + (size_t)b * (a.cin / 16) * in_plane;
-        ld_w = a.w + (size_t)cg * BN * 16;
-#pragma unroll
-        for (int i = 0; i < NPXU; ++i) {
-            const int u = i * NTHR + tid;
-            int off = -1;
-            if (u < PXU_TOTAL) {
-                const int kk = u / (2 * IN_PIX);
-                const int v = u % (2 * IN_PIX);
-                const int P = v >> 1, h = v & 1;
-                const int iy = y0 * STRIDE - PAD + P / IN_W;
-                const int ix = x0 * STRIDE - PAD + P % IN_W;
-                if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-                    off = (int)(kk * in_plane) + (iy * a.win + ix) * 32 + h * 16;
-            }
-            px_off[i] = off;
-        }
-    };
-    int w_off[NWU];
-#pragma unroll
-    for (int i = 0; i < NWU; ++i) {
-        const int u = i * NTHR + tid;
-        const int r = u % BN, th = u / BN;
-        w_off[i] = (th * CP + r) * 16;
-    }
-    uint4 rpx[NPXU];
-    auto dma_filters = [&](int s, int buf) {
-        const uint8_t* wp = ld_w + (size_t)s * w_stage_stride;
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            if (i * NTHR + wave * 64 < WU_TOTAL) {  // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + w_off[i]),
-                                                 (__attribute__((address_space(3))) void*)(lds + buf * BUF_BYTES + W_BASE +
-                                                                                           (i * NTHR + wave * 64) * 16),
-                                                 16, 0, 0);
-            }
-        }
-    };
-    auto load_pixels = [&](int s) {
-        const uint8_t* sp = ld_src + (size_t)s * NK * in_plane;
-#pragma unroll
-        for (int i = 0; i < NPXU; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (px_off[i] >= 0) v = *reinterpret_cast<const uint4*>(sp + px_off[i]);
-            rpx[i] = v;
-        }
-    };
-    auto store_pixels = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NPXU; ++i) {
-            const int u = i * NTHR + tid;
-            if (u < PXU_TOTAL) {
-                const int kk = u / (2 * IN_PIX);
-                const int v = u % (2 * IN_PIX);
-                const int P = v >> 1, h = v & 1;
-                *reinterpret_cast<uint4*>(lds + buf * BUF_BYTES + kk * PIX_SLAB + (h * IN_PIX + P) * 16) = rpx[i];
-            }
-        }
-    };
-
-    int pb[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int p = (wn * NT + n) * 32 + c;
-        const int ty = p / TW, tx = p % TW;
-        pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
-    }
-    const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
-    const int nstages = a.cin / (16 * NK);
-
-    setup_loader(item);
-    dma_filters(0, 0);
-    load_pixels(0);
-    store_pixels(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    while (true) {
-        // the item the MFMAs work on
-        const int cg = item % a.n_cgroups;
-        const int pt = item / a.n_cgroups;
-        const int b = pt / tiles_per_img;
-        const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
-        const int next_item = item + slots;
-        const bool has_next = next_item < last;
-
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        ResRegs<MT, NT> rr;
-
-        for (int s = 0; s < nstages; ++s) {
-            const bool last_stage = (s + 1 == nstages);
-            const bool more = !last_stage || has_next;
-            if (!AY_DBGBIT(a, 1)) {
-                if (!last_stage) {
-                    load_pixels(s + 1);
-                    dma_filters(s + 1, cur ^ 1);
-                } else if (has_next) {
-                    setup_loader(next_item);
-                    load_pixels(0);
-                    dma_filters(0, cur ^ 1);
-                }
-            }
-            if (last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
-            const uint8_t* L = lds + cur * BUF_BYTES;
-            // fragments of step t+1 are requested before the MFMAs of step t issue (one full step of MFMA time to land)
-            constexpr int NSTEP = NK * KK2;
-            bf16x8 af[2][MT], bfr[2][NT];
-            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
-                const int kk = t / KK2, tap = t % KK2;
-                const int kh = tap / KS, kw = tap % KS;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    fa[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
-            };
-            if (!AY_DBGBIT(a, 2)) load_frags(0, af[0], bfr[0]);
-#pragma unroll
-            for (int t = 0; t < NSTEP; ++t) {
-                if (AY_DBGBIT(a, 2)) break;
-                if (t + 1 < NSTEP) load_frags(t + 1, af[(t + 1) & 1], bfr[(t + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) {
-                store_pixels(cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage's filter DMA has landed
-                __syncthreads();
-            }
-            cur ^= 1;
-        }
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
-        if (!has_next) break;
-        item = next_item;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// V4: persistent, ALL staging by LDS-DMA into a ring of NBUF stage buffers, counted vmcnt, raw s_barrier.
+// Ring kernel: persistent, ALL staging by LDS-DMA into a ring of NBUF stage buffers, counted vmcnt, raw s_barrier.
 //   * input pixels too go global -> LDS by DMA: lanes whose pixel falls outside the image (3x3 halo at the border,
 //     ragged tiles) read from a 64-byte page of zeros instead (the DMA source address is per lane);
 //   * stage g+NBUF-1 is issued before the MFMAs of stage g: NBUF-1 stages of DMA in flight per CU, which is what
@@ -584,7 +198,8 @@ __device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];  // zero-initi
 // [3] workgroups, [4] whole-kernel ticks per workgroup, [5] first stages, [6] slowest workgroup; 100 MHz ticks (s_memrealtime)
 __device__ unsigned long long g_phase_ticks[8];
 // dynamic item dealing: 64 rotating sets of {8 per-XCD item counters, exit counter}; zero at load, reset by the last workgroup
-__device__ unsigned g_deal[64][16];
+constexpr int DEAL_SETS = 64, DEAL_STREAMS = 16;
+__device__ unsigned g_deal[DEAL_STREAMS * DEAL_SETS][16];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
@@ -943,23 +558,57 @@ constexpr int ring_depth() {
     return (3 * buf + 1024 + 4 * (BN > 128 ? 2048 : 1024) + 64 <= 160 * 1024) ? 3 : 2;
 }
 
-// AY_CONV_MODE: 1 = V1 (4 waves, register staging), 2 = V2 (8 waves, DMA filters), 3 = V3 persistent,
-// 4 = V4 persistent all-DMA ring (default)
-static int conv_mode() {
-    static const int m = getenv("AY_CONV_MODE") ? atoi(getenv("AY_CONV_MODE")) : 4;
-    return m;
+static int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev < 0 || dev >= 64 ? 0 : dev;
 }
 int conv_num_cus() {
-    static int n = 0;
+    static std::atomic<int> cus[64];  // per device
+    const int dev = current_device();
+    int n = cus[dev].load(std::memory_order_relaxed);
     if (!n) {
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n < 8) n = 256;
         if (getenv("AY_CUS")) n = atoi(getenv("AY_CUS"));  // timing experiments only
         n -= n % 8;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
     return n;
+}
+
+// Counter set of the next ring-kernel launch on `st` (nullptr: static dealing).  The sets of one stream are used in rotation
+// by launches that the stream serialises -- the last workgroup of a launch hands its set back zeroed before the next launch
+// on that stream starts -- so a set must never be shared by two streams, whose launches may overlap: every (device, stream)
+// pair owns DEAL_SETS sets of its own, up to DEAL_STREAMS streams per device; further streams deal statically.  A set pointer
+// baked into a captured graph node stays valid under the same rule: replay the graph on the stream it was captured on, or on
+// any stream as long as nothing else on the CAPTURE stream runs concurrently.
+unsigned* next_deal_set(hipStream_t st) {
+    static const int dynamic = getenv("AY_DYNAMIC") ? atoi(getenv("AY_DYNAMIC")) : 1;
+    if (!dynamic) return nullptr;
+    struct PerDevice {
+        unsigned* base = nullptr;
+        hipStream_t streams[DEAL_STREAMS] = {};
+        unsigned seq[DEAL_STREAMS] = {};
+        int n = 0;
+    };
+    static std::mutex mu;
+    static PerDevice devs[64];
+    std::lock_guard<std::mutex> lock(mu);
+    PerDevice& pd = devs[current_device()];
+    if (!pd.base) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_deal)) != hipSuccess) return nullptr;  // this device's copy of the symbol
+        pd.base = (unsigned*)p;
+    }
+    int k = 0;
+    while (k < pd.n && pd.streams[k] != st) ++k;
+    if (k == pd.n) {
+        if (pd.n == DEAL_STREAMS) return nullptr;
+        pd.streams[pd.n++] = st;
+    }
+    return pd.base + ((size_t)k * DEAL_SETS + (pd.seq[k]++ % DEAL_SETS)) * 16;
 }
 
 // canvas tiling (ConvArgs::canvas_gx) applies to stride-1 same-size layers that save tiles that way and whose tensors stay below
@@ -987,10 +636,8 @@ static int canvas_plan(const ay_conv_desc* d, int th, int tw, int* tiles_x, int*
     return best * 10 <= image_tiles * 9 ? best_gx : 0;  // worth it from a tenth fewer tiles
 }
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool V2 = false>
-static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
-                  const void* residual, void* out, hipStream_t st) {
-    ConvArgs a;
+static void fill_args(ConvArgs& a, const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
+                      const void* residual, void* out, int TH, int TW, int BN) {
     a.src = (const uint8_t*)src;
     a.w = (const uint8_t*)w;
     a.scale = scale;
@@ -1008,30 +655,28 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     a.tiles_y = (d->hout + TH - 1) / TH;
     a.n_cgroups = d->cout_pad / BN;
     a.leaky = d->leaky;
+    a.dbg = 0;
+    a.stagger = 0;
+    a.deal = nullptr;
+    a.src1 = nullptr;
+    a.c1 = 0;
+    a.canvas_gx = 0;
+}
+
+// RING = false: the 4-wave register-staged kernel (fp32-output heads, cout_pad not a multiple of 64); RING = true: the persistent
+// all-DMA ring kernel
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool RING = false>
+static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
+                  const void* residual, void* out, hipStream_t st) {
+    ConvArgs a;
+    fill_args(a, d, src, w, scale, shift, residual, out, TH, TW, BN);
     static const int dbg = getenv("AY_DBG") ? atoi(getenv("AY_DBG")) : 0;
     a.dbg = dbg;
     static const int stagger = getenv("AY_STAGGER") ? atoi(getenv("AY_STAGGER")) : 0;
     a.stagger = stagger;
-    a.deal = nullptr;
-    a.src1 = nullptr;
-    a.c1 = 0;
-    if (V2 && conv_mode() >= 4) {
-        static const int dynamic = getenv("AY_DYNAMIC") ? atoi(getenv("AY_DYNAMIC")) : 1;
-        static unsigned* deal_base = nullptr;
-        static std::atomic<unsigned> deal_seq{0};
-        if (dynamic && !deal_base) {
-            void* p = nullptr;
-            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_deal)) == hipSuccess) deal_base = (unsigned*)p;
-        }
-        // (the 1x1 kernels once measured 5-20 % slower with dynamic dealing: that was the flat-addressed mailbox draining the DMA
-        // ring, not the counter fetch; with the LDS-typed mailbox they gain slightly, AY_DYN1=0 turns it off for them)
-        static const int dyn1 = getenv("AY_DYN1") ? atoi(getenv("AY_DYN1")) : 1;
-        if (dynamic && deal_base && (KS == 3 || dyn1)) a.deal = deal_base + (deal_seq.fetch_add(1) & 63) * 16;
-    }
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
-    a.canvas_gx = 0;
     int ctx = 0, cty = 0;
-    if (V2 && conv_mode() >= 4 && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
+    if (RING && (a.canvas_gx = canvas_plan(d, TH, TW, &ctx, &cty)) > 0) {
         // images that leave much of their tiles empty: tile a canvas of gx images per row with one-pixel gutters instead
         a.tiles_x = ctx;
         a.tiles_y = cty;
@@ -1043,48 +688,38 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         set_error("conv grid out of range (%lld)", nblk);
         return AY_ERR_ARG;
     }
-    dim3 grid((unsigned)nblk), block(V2 ? 512 : 256);
-    if constexpr (V2) {
-        static_assert(!OUT_F32 || !V2, "V2 is instantiated for bf16 outputs only");
-        if (conv_mode() >= 4) {  // persistent all-DMA ring
-            const int per_xcd = (int)((nblk + 7) / 8);
-            const int cu_slots = conv_num_cus() / 8;
-            dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
-            constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
-            constexpr bool CV = true;
-            if (a.canvas_gx && residual)
-                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, CV>), pgrid, block, 0, st, a, (int)nblk);
-            else if (a.canvas_gx)
-                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, CV>), pgrid, block, 0, st, a, (int)nblk);
-            else if (residual)
-                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
-            else
-                hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
-        } else if constexpr (TH * TW > 256) {
-            set_error("16x32 tile exists for the ring kernel only");
-            return AY_ERR_ARG;
-        } else if (conv_mode() == 3) {  // persistent: one workgroup per CU, items dealt per XCD
-            const int per_xcd = (int)((nblk + 7) / 8);
-            const int cu_slots = conv_num_cus() / 8;
-            dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
-            if (residual)
-                hipLaunchKernelGGL((conv_bf16_persist_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true>), pgrid, block, 0, st, a, (int)nblk);
-            else
-                hipLaunchKernelGGL((conv_bf16_persist_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false>), pgrid, block, 0, st, a, (int)nblk);
-        } else if (residual)
-            hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
+    if constexpr (RING) {
+        static_assert(!OUT_F32, "the ring kernel writes bf16");
+        // (the 1x1 kernels once measured 5-20 % slower with dynamic dealing: that was the flat-addressed mailbox draining the DMA
+        // ring, not the counter fetch; with the LDS-typed mailbox they gain slightly, AY_DYN1=0 turns it off for them)
+        static const int dyn1 = getenv("AY_DYN1") ? atoi(getenv("AY_DYN1")) : 1;
+        if (KS == 3 || dyn1) a.deal = next_deal_set(st);
+        const int per_xcd = (int)((nblk + 7) / 8);
+        const int cu_slots = conv_num_cus() / 8;
+        dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots))), block(512);
+        constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
+        if (a.canvas_gx && residual)
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, true>), pgrid, block, 0, st, a, (int)nblk);
+        else if (a.canvas_gx)
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, true>), pgrid, block, 0, st, a, (int)nblk);
+        else if (residual)
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
         else
-            hipLaunchKernelGGL((conv_bf16_dma_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
-    } else if constexpr (OUT_F32) {
-        hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
     } else {
-        if (residual)
-            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
-        else
-            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
+        dim3 grid((unsigned)nblk), block(256);
+        if constexpr (OUT_F32) {
+            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false>), grid, block, 0, st, a);
+        } else {
+            if (residual)
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
+            else
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
+        }
     }
     AY_CHECK_LAUNCH("conv_bf16_kernel");
-    if (V2 && (dbg & 8) && conv_mode() >= 4) {  // timing experiments only: synchronous phase report per launch
+#ifdef AY_PHASE_CLOCK
+    if (RING && (dbg & 8)) {  // timing experiments only: synchronous phase report per launch
         unsigned long long t[8] = {0};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
@@ -1095,6 +730,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
     }
+#endif
     return AY_OK;
 }
 
@@ -1106,28 +742,9 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
                           const float* shift, void* out, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NK = 4;
     ConvArgs a;
-    a.src = (const uint8_t*)src2;
+    fill_args(a, d, src2, w, scale, shift, nullptr, out, TH, TW, BN);
     a.src1 = (const uint8_t*)src1;
     a.c1 = c1;
-    a.w = (const uint8_t*)w;
-    a.scale = scale;
-    a.shift = shift;
-    a.residual = nullptr;
-    a.out = (uint8_t*)out;
-    a.batch = d->batch;
-    a.cin = d->cin;
-    a.cout_pad = d->cout_pad;
-    a.hin = d->hin;
-    a.win = d->win;
-    a.hout = d->hout;
-    a.wout = d->wout;
-    a.tiles_x = (d->wout + TW - 1) / TW;
-    a.tiles_y = (d->hout + TH - 1) / TH;
-    a.n_cgroups = d->cout_pad / BN;
-    a.leaky = d->leaky;
-    a.dbg = 0;
-    a.stagger = 0;
-    a.deal = nullptr;
     long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     a.canvas_gx = 0;
     int ctx = 0, cty = 0;
@@ -1187,23 +804,21 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
     const int cp = d->cout_pad;
     if (d->ksize == 3 && d->stride == 1) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
-        const int v1 = conv_mode() == 1;
         static const int tile16 = getenv("AY_TILE16") ? atoi(getenv("AY_TILE16")) : 1;
-        if (cp % 128 == 0 && !v1 && tile16 && conv_mode() >= 4 && d->hout >= 16)
+        static const int m16 = getenv("AY_M16") ? atoi(getenv("AY_M16")) : 1;
+        int ctx = 0, cty = 0;
+        if (cp % 128 == 0 && tile16 && m16 && d->hout >= 16 && d->cin % 32 == 0 && canvas_plan(d, 16, 32, &ctx, &cty) == 0)
+            return ay_conv3x3_m16_fwd_bf16(d, src, w_packed, scale, shift, residual, out, stream);  // v_mfma_f32_16x16x32_bf16
+        if (cp % 128 == 0 && tile16 && d->hout >= 16)
             return launch<3, 1, 128, 2, 4, 16, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 128 == 0 && !v1) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0 && !v1) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 128 == 0) return launch<3, 1, 128, 2, 2, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<3, 1, 64, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 128 == 0) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<3, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
     }
     if (d->ksize == 3 && d->stride == 2) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
-        const int v1 = conv_mode() == 1;
-        if (cp % 128 == 0 && !v1) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0 && !v1) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 128 == 0) return launch<3, 2, 128, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<3, 2, 64, 2, 2, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 128 == 0) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<3, 2, 32, 1, 4, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
     }
     // 1x1
@@ -1212,14 +827,11 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
             return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
         }
-        const int v1 = conv_mode() == 1;
         static const int bn256 = getenv("AY_BN256") ? atoi(getenv("AY_BN256")) : 1;
-        if (cp % 256 == 0 && !residual && conv_mode() >= 4 && bn256)
+        if (cp % 256 == 0 && !residual && bn256)
             return launch_ring1x1<256, 4, 2, false>(d, nullptr, 0, src, w_packed, scale, shift, out, st);
-        if (cp % 128 == 0 && !v1) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0 && !v1) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 128 == 0) return launch<1, 1, 128, 2, 2, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 128 == 0) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         return launch<1, 1, 32, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
     }
     if (d->out_f32) return launch<1, 1, 32, 1, 4, 8, 32, 1, true>(d, src, w_packed, scale, shift, residual, out, st);

@@ -275,5 +275,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 }
 
 int conv_num_cus();
+// counter set for the dynamic item dealing of the next ring-kernel launch on `st` (nullptr: static dealing); ay_conv_bf16.hip
+unsigned* next_deal_set(hipStream_t st);
 
 }  // namespace ay

@@ -46,6 +46,18 @@ def parse():
     return ap.parse_args()
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: profiles/traffic.json records the value it was measured on, and a
+    traffic figure from other sources is not reported (the GPU box has no .git to ask for a commit)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "amyloid_yolo_paper_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def conv_flops(e, B, S):
     h = S >> e["log2_down"]
     return 2.0 * B * h * h * e["cout"] * e["cin"] * e["k"] * e["k"]
@@ -204,20 +216,25 @@ def main():
             ms = sum(events)
             launches = len(events) * a.steps
             achieved = fam_flops * a.steps / (ms * 1e-3) / 1e12
-            traffic = None
+            traffic, traffic_note = None, "no profiles/traffic.json"
             try:
-                traffic = json.load(open(a.traffic_json)).get("conv3x3s1_bn128_bytes_per_launch")
+                tj = json.load(open(a.traffic_json))
+                if tj.get("csrc_sha16") == csrc_sha16():
+                    traffic, traffic_note = tj.get("conv3x3s1_bn128_bytes_per_launch"), tj.get("source")
+                else:
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources (csrc_sha16 differs): not reported"
             except Exception:
                 pass
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "ay::conv_bf16_ring_kernel<3,1,128,2,4,16,32,1,2,res|nores> (3x3 s1, 128 ch x 512 px tile, persistent LDS-DMA ring)",
                 "launches_per_step": launches // a.steps, "avg_launch_ms": round(ms / launches, 4),
                 "flops_per_launch": fam_flops / (launches // a.steps), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
             }
         if not a.no_cpu_baseline and a.gpus == 1:
-            result["cpu_baseline"] = cpu_baseline(a, cfg, params)
+            result["cpu_baseline"], ref_dets, ref_tiles = cpu_baseline(a, cfg, params)
+            result["parity"] = parity_vs_cpu(a, model, ref_dets, ref_tiles)
         print(json.dumps(result), flush=True)
     if USE_DIST:
         dist.barrier()
@@ -308,8 +325,10 @@ def host_cores():
 
 
 def cpu_baseline(a, cfg, params):
-    """The CPU oracle (port of the reference's CPU path) on a bounded sample of the same tiles: batch 1, as many
-    tiles as fit in ~20 s (at most --cpu_tiles), on the host cores of this box."""
+    """The CPU oracle (port of the reference's CPU path, pinned to it by tests/golden) on a bounded sample of the same
+    workload, on the host cores of this box, by the protocol of BASELINE.md section 3 (which mirrors validation.speedCheck:
+    data loading excluded): --cpu_tiles synthetic tiles at batch 1 in >= 3 timed passes after a warm-up, then the same tiles
+    at batch 8.  Returns (json dict, per-tile reference detections, the tiles)."""
     import torch
     from amyloid_yolo_paper_amd import synth
     from oracle import boxes_oracle as bo
@@ -319,22 +338,66 @@ def cpu_baseline(a, cfg, params):
     m = OracleDarknet(cfg)
     m.set_params(params)
     tiles = torch.from_numpy(synth.synth_tiles(a.cpu_tiles, a.size, start=0))
+    dets = []
     with torch.no_grad():
         tw = time.perf_counter()
         m.forward(tiles[:1])  # warm-up, also sizes the sample
         warm = time.perf_counter() - tw
-        n = max(1, min(a.cpu_tiles, int(20.0 / max(warm, 1e-3))))
-        t0 = time.perf_counter()
-        t_nms = 0.0
-        for i in range(n):
-            out = m.forward(tiles[i:i + 1]).numpy()
-            t2 = time.perf_counter()
-            bo.non_max_suppression(out, a.conf_thres, a.nms_thres)
-            t_nms += time.perf_counter() - t2
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the same synthetic {a.size}x{a.size} tiles, batch 1, fp32 torch-CPU conv stack + restated decode/merge-NMS "
-                      f"({dt:.1f} s total, NMS {t_nms:.2f} s)"}
+        n = max(4, min(a.cpu_tiles, int(24.0 / max(warm, 1e-3)))) if a.cpu_tiles >= 4 else a.cpu_tiles
+        n_pass = 4 if n >= 4 else 1
+        per = n // n_pass
+        n = per * n_pass
+        pass_rates, t_model, t_nms = [], 0.0, 0.0
+        for p in range(n_pass):
+            t0 = time.perf_counter()
+            for i in range(p * per, (p + 1) * per):
+                t1 = time.perf_counter()
+                out = m.forward(tiles[i:i + 1]).numpy()
+                t2 = time.perf_counter()
+                rows, keep, _ = bo.non_max_suppression(out, a.conf_thres, a.nms_thres)
+                t3 = time.perf_counter()
+                t_model += t2 - t1
+                t_nms += t3 - t2
+                dets.append((keep[0], rows[0]))
+            pass_rates.append(per / (time.perf_counter() - t0))
+        b1 = n / (t_model + t_nms)
+        # batch 8 over the same tiles (at most 16 s of it)
+        b8, nb8 = None, 0
+        if n >= 8:
+            t0 = time.perf_counter()
+            for i in range(0, n - 7, 8):
+                out = m.forward(tiles[i:i + 8]).numpy()
+                bo.non_max_suppression(out, a.conf_thres, a.nms_thres)
+                nb8 += 8
+                if time.perf_counter() - t0 > 16.0:
+                    break
+            b8 = nb8 / (time.perf_counter() - t0)
+    best = max(b1, b8 or 0.0)
+    res = {"value": round(best, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+           "batch1_tiles_per_s": round(b1, 4), "batch8_tiles_per_s": None if b8 is None else round(b8, 4),
+           "batch1_passes_tiles_per_s": [round(r, 4) for r in pass_rates],
+           "sample": f"{n} of the same synthetic {a.size}x{a.size} tiles: batch 1 in {n_pass} timed passes of {per} after a warm-up "
+                     f"(model {t_model:.1f} s, decode+merge-NMS {t_nms:.2f} s), then {nb8} of them at batch 8; fp32 torch-CPU conv stack "
+                     f"+ restated decode/merge-NMS on {cores} threads; value = the faster of the two batch sizes"}
+    return res, dets, tiles[:n]
+
+
+def parity_vs_cpu(a, model, ref_dets, tiles):
+    """The timed (bf16) path against the CPU oracle's detections on the cpu_baseline sample: share of the oracle's kept box
+    indices it reproduces, largest box / confidence difference over the matched heads (oracle/parity.py).  The bars this is held
+    to, and why a path that stores bf16 activations cannot match every index, are in tests/test_gpu_configs.py."""
+    import torch
+    from amyloid_yolo_paper_amd.utils import non_max_suppression
+    from oracle import parity
+    items = []
+    with torch.no_grad():
+        for i, (keep, rows) in enumerate(ref_dets):
+            out = model.forward_device(tiles[i:i + 1]).clone()
+            res = non_max_suppression(out, a.conf_thres, a.nms_thres)
+            got = None if res[0] is None else res[0].cpu().numpy()
+            items.append(parity.detection_agreement(keep, rows, res.keep_idx[0], got))
+    return dict(parity.summarize(items), against="CPU oracle (fp32, = the reference's CPU path on tests/golden), same tiles, "
+                                                  "conf %.2f nms %.2f" % (a.conf_thres, a.nms_thres))
 
 
 if __name__ == "__main__":

@@ -80,6 +80,13 @@ int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const flo
 int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
                      const float* shift, const void* residual, void* out, ay_stream_t stream);
 
+/* The 3x3 stride-1 member of ay_conv_fwd_bf16 for cout_pad % 128 == 0, cin % 32 == 0, at least 16 output rows: the same
+ * block (models.py:26-45, 246-248) on v_mfma_f32_16x16x32_bf16, which the chip clocks higher than the 32x32x16 form on
+ * non-trivial data.  ay_conv_fwd_bf16 dispatches to it (AY_M16=0 in the environment keeps the 32x32x16 kernel); same
+ * arguments, same rounding contract (bf16 operands, fp32 accumulation in a different order, one rounding per output). */
+int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                            const void* residual, void* out, ay_stream_t stream);
+
 /* The same 1x1 convolution over a route that is never materialised (models.py:86-96,244-245): input channels
  * [0, c1) come from src1_halfres ([B][c1/16][H/2][W/2][16], nearest x2 upsample folded into the loader), channels
  * [c1, cin) from src2 ([B][(cin-c1)/16][H][W][16]); c1 and cin-c1 multiples of 64, cout_pad a multiple of 128. */

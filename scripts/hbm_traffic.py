@@ -48,7 +48,9 @@ for (n, fv), (n2, wv) in zip(fs, ws):
 print(f"total fetch {tf/1e3:.2f} GB  write {tw/1e3:.2f} GB  algorithmic {ti/1e3:.2f} GB")
 print(f"3x3 s1 128-channel family: {fam_n} launches, {fam_bytes/fam_n/1e6:.1f} MB HBM traffic per launch")
 if "--json" in sys.argv:
+    import bench
     json.dump({"conv3x3s1_bn128_bytes_per_launch": round(fam_bytes / fam_n),
+               "csrc_sha16": bench.csrc_sha16(), "git_head": os.environ.get("AY_GIT_HEAD", "unknown"),
                "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, bench.py B=64",
                "total_fetch_gb_per_step": round(tf / 1e3, 2), "total_write_gb_per_step": round(tw / 1e3, 2)},
               open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

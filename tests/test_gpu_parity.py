@@ -159,6 +159,12 @@ CONV_CASES = [
     (128, 256, 3, 2, 26, True, False, False, 5),   # stride 2 on the canvas: 13x13 outputs, input cells twice as large
     (64, 128, 3, 2, 52, True, False, False, 3),    # BN=128, 26x26 outputs
     (32, 64, 3, 2, 16, True, False, False, 9),     # BN=64, 8x8 outputs
+    # 16x16x32-MFMA kernel (3x3 s1, cout % 128 == 0, cin % 32 == 0, >= 16 rows, no canvas): tap pairs + the two-stage straddle
+    (128, 256, 3, 1, 40, True, True, False, 2),    # ragged 40: tile rows 16+16+8, columns 32+8; residual (deferred stores)
+    (64, 128, 3, 1, 48, True, False, False, 3),    # two stages only (one straddle), three images
+    (256, 512, 3, 1, 16, True, True, False, 2),    # exactly one tile row; 4 channel groups; 16 stages
+    (128, 128, 3, 1, 20, False, True, False, 1),   # linear, batch 1
+    (32, 128, 3, 1, 33, True, False, False, 2),    # a single stage pair, 33 = one pixel into the second tile column / third row
 ]
 
 
