@@ -33,6 +33,16 @@
 
 namespace ay {
 
+#ifdef AY_PHASE_CLOCK
+// instrumented build only (AY_PHASE_CLOCK=1 python build.py, AY_DBG=8 at run time): 100 MHz ticks of wave 0, summed over
+// workgroups: [0] stage loops, [1] epilogues, [2] items, [3] workgroups, [4] whole kernel per workgroup, [5] waits for landed
+// stages (vmcnt + barrier, both kinds), [6] slowest workgroup, [7] straddle step + its barrier
+__device__ unsigned long long g_phase_ticks_m16[8];
+#define AY_CLK(...) __VA_ARGS__
+#else
+#define AY_CLK(...)
+#endif
+
 template <bool HAS_RES>
 __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, int n_items) {
     constexpr int BN = 128, TH = 16, TW = 32;
@@ -182,7 +192,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
     asm volatile("" ::: "memory");
 
     int par = 0;
+    AY_CLK(const bool clk = (a.dbg & 8) && wave == 0; unsigned long long tk_stage = 0, tk_epi = 0, tk_items = 0, tk_wait = 0, tk_str = 0, tk0 = 0, tkw = 0;
+           const unsigned long long tk_begin = wall_clock64();)
     while (true) {
+        AY_CLK(if (clk) tk0 = wall_clock64();)
         const int cg = item % a.n_cgroups;
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
@@ -212,10 +225,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
         // one K32-step: 32 MFMAs; behind the MFMAs of pixel tile n its fragment register takes the next step's tile n, the
         // filter fragments of the next step go to the other register set; PREFETCH = false where the next step's slot has not
         // landed yet (the step in front of a stage barrier): its fragments are then loaded after the barrier
-        auto step = [&](auto KIND, auto SL, auto NKIND, auto NSL, auto CUR, auto PREFETCH, bool dma, int dma_slot, int piece0) __attribute__((always_inline)) {
+        // DMA pieces ride behind the MFMA groups 1, 3, 5, 7 of a step: PLIST 0 = none, 1 = pieces 0..3, 2 = pieces 4..7,
+        // 3 = the early pieces 3..6 (filter taps 0..7), 4 = the late pieces 0, 1, 2, 7 (pixels, tap 8, scale/shift)
+        auto step = [&](auto KIND, auto SL, auto NKIND, auto NSL, auto CUR, auto PREFETCH, auto PLIST, bool dma, int dma_slot) __attribute__((always_inline)) {
             constexpr int kind = decltype(KIND)::value, sl = decltype(SL)::value, nkind = decltype(NKIND)::value, nsl = decltype(NSL)::value;
             constexpr int cur = decltype(CUR)::value;
             constexpr bool prefetch = decltype(PREFETCH)::value;
+            constexpr int plist = decltype(PLIST)::value;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 __builtin_amdgcn_s_setprio(3);
@@ -224,12 +240,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
                 __builtin_amdgcn_s_setprio(2);
                 if (n < 4) {
                     fb[n & 3] = ld_b(kind, sl, n + 4);
+                    // the next step's first MFMA group needs all four filter fragments: they are requested in the first half of
+                    // this step (behind groups 4..7 the last of them was waited for at every step boundary)
+                    if constexpr (prefetch) fa[cur ^ 1][n] = ld_a(nkind, nsl, n);
                 } else if constexpr (prefetch) {
                     fb[n & 3] = ld_b(nkind, nsl, n - 4);
-                    fa[cur ^ 1][n - 4] = ld_a(nkind, nsl, n - 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (dma && (n == 3 || n == 7)) issue_piece(piece0 + (n >> 2), dma_slot);
+                if constexpr (plist != 0) {
+                    if (dma && (n & 1)) {
+                        const int j = n >> 1;  // 0..3 (n is a constant after unrolling)
+                        const int piece = plist == 1 ? j : plist == 2 ? 4 + j : plist == 3 ? 3 + j : (j < 3 ? j : 7);
+                        issue_piece(piece, dma_slot);
+                    }
+                }
             }
         };
         auto load_all = [&](auto KIND, auto SL, auto CUR) __attribute__((always_inline)) {
@@ -250,34 +274,43 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
         load_all(I0{}, I0{}, I0{});
         for (int s = 0; s < nstages; s += 2) {
             const bool last_pair = s + 2 == nstages;
-            // ---- even stage (slot 0); the odd stage of this item streams into slot 1 behind the MFMA groups
-            step(I0{}, I0{}, I1{}, I0{}, I0{}, T{}, true, 1, 0);
-            step(I1{}, I0{}, I2{}, I0{}, I1{}, T{}, true, 1, 2);
-            step(I2{}, I0{}, I3{}, I0{}, I0{}, T{}, true, 1, 4);
-            step(I3{}, I0{}, I4{}, I0{}, I1{}, F{}, true, 1, 6);
+            // ---- even stage (slot 0).  The odd stage of this item streams into slot 1, all of it issued in the first two steps:
+            // an LDS-DMA piece lands ~1.1 us after its issue under load, about two steps; spread evenly over the stage the last
+            // pieces were waited for 0.85 us at every stage end (phase clock: 27 % of the stage loop).
+            step(I0{}, I0{}, I1{}, I0{}, I0{}, T{}, I1{}, true, 1);
+            step(I1{}, I0{}, I2{}, I0{}, I1{}, T{}, I2{}, true, 1);
+            step(I2{}, I0{}, I3{}, I0{}, I0{}, T{}, I0{}, false, 1);
+            step(I3{}, I0{}, I4{}, I0{}, I1{}, F{}, I0{}, false, 1);
             advance_loader();
+            AY_CLK(if (clk) tkw = wall_clock64();)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the odd stage has landed
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // ---- tap 8 of both stages in one K32-step
-            load_all(I4{}, I0{}, I0{});
-            step(I4{}, I0{}, I0{}, I1{}, I0{}, T{}, false, 0, 0);
-            __builtin_amdgcn_s_barrier();  // every wave is through with slot 0: the next stage may stream into it
-            asm volatile("" ::: "memory");
-            // ---- odd stage (slot 1); stage s+2 of this item, or stage 0 of the next, streams into slot 0
+            AY_CLK(if (clk) { const unsigned long long t = wall_clock64(); tk_wait += t - tkw; tkw = t; })
+            // ---- tap 8 of both stages in one K32-step.  Every wave is through with the filter taps 0..7 of slot 0 (barrier
+            // above), the straddle reads tap 8 and the pixels only: the next stage's taps 0..7 stream into slot 0 already
             const bool issued = !ld_done;
-            step(I0{}, I1{}, I1{}, I1{}, I1{}, T{}, issued, 0, 0);
-            step(I1{}, I1{}, I2{}, I1{}, I0{}, T{}, issued, 0, 2);
-            step(I2{}, I1{}, I3{}, I1{}, I1{}, T{}, issued, 0, 4);
-            step(I3{}, I1{}, I0{}, I0{}, I0{}, F{}, issued, 0, 6);
+            load_all(I4{}, I0{}, I0{});
+            step(I4{}, I0{}, I0{}, I1{}, I0{}, T{}, I3{}, issued, 0);
+            __builtin_amdgcn_s_barrier();  // every wave is through with slot 0: its pixels and tap 8 may follow
+            asm volatile("" ::: "memory");
+            AY_CLK(if (clk) tk_str += wall_clock64() - tkw;)
+            // ---- odd stage (slot 1); the rest of stage s+2 of this item, or of stage 0 of the next, streams into slot 0
+            step(I0{}, I1{}, I1{}, I1{}, I1{}, T{}, I4{}, issued, 0);
+            step(I1{}, I1{}, I2{}, I1{}, I0{}, T{}, I0{}, false, 0);
+            step(I2{}, I1{}, I3{}, I1{}, I1{}, T{}, I0{}, false, 0);
+            step(I3{}, I1{}, I0{}, I0{}, I0{}, F{}, I0{}, false, 0);
             if (issued) advance_loader();
             if (!(last_pair && !has_next)) {
+                AY_CLK(if (clk) tkw = wall_clock64();)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next even stage has landed
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                AY_CLK(if (clk) tk_wait += wall_clock64() - tkw;)
                 if (!last_pair) load_all(I0{}, I0{}, I0{});
             }
         }
+        AY_CLK(if (clk) { const unsigned long long t = wall_clock64(); tk_stage += t - tk0; tk0 = t; })
 
         int fetched = last;
         if (tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);
@@ -374,12 +407,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
             mbox[(seq_c + D) & 7] = fetched;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        AY_CLK(if (clk) { tk_epi += wall_clock64() - tk0; ++tk_items; })
         if (!has_next) break;
         item = next_item;
         ++seq_c;
         par = (par + 1) & 3;
     }
     leave();
+    AY_CLK(if (clk && lane == 0) {
+        const unsigned long long tot = wall_clock64() - tk_begin;
+        atomicAdd(&g_phase_ticks_m16[0], tk_stage); atomicAdd(&g_phase_ticks_m16[1], tk_epi); atomicAdd(&g_phase_ticks_m16[2], tk_items);
+        atomicAdd(&g_phase_ticks_m16[3], 1ull); atomicAdd(&g_phase_ticks_m16[4], tot); atomicAdd(&g_phase_ticks_m16[5], tk_wait);
+        atomicMax(&g_phase_ticks_m16[6], tot); atomicAdd(&g_phase_ticks_m16[7], tk_str);
+    })
 }
 
 }  // namespace ay
@@ -415,6 +455,10 @@ extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, c
     a.n_cgroups = d->cout_pad / 128;
     a.leaky = d->leaky;
     a.dbg = 0;
+#ifdef AY_PHASE_CLOCK
+    static const int dbg = getenv("AY_DBG") ? atoi(getenv("AY_DBG")) : 0;
+    a.dbg = dbg;
+#endif
     a.stagger = 0;
     a.src1 = nullptr;
     a.c1 = 0;
@@ -434,5 +478,18 @@ extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, c
     else
         hipLaunchKernelGGL((conv3x3_m16_ring_kernel<false>), pgrid, dim3(512), 0, st, a, (int)nblk);
     AY_CHECK_LAUNCH("conv3x3_m16_ring_kernel");
+#ifdef AY_PHASE_CLOCK
+    if (a.dbg & 8) {  // timing experiments only: synchronous phase report per launch
+        unsigned long long t[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks_m16), sizeof(t));
+        if (t[3])
+            fprintf(stderr, "[ay phase m16] cin%d cout%d h%d res%d: items/wg %.1f  per item: stages %.2f us (of it waits for landed stages %.2f, straddle+barrier %.2f; %d stages), epilogue %.2f us; wg total %.1f us (slowest %.1f)\n",
+                    d->cin, d->cout, d->hout, residual ? 1 : 0, (double)t[2] / t[3], t[0] * 0.01 / t[2], t[5] * 0.01 / t[2], t[7] * 0.01 / t[2],
+                    d->cin / 16, t[1] * 0.01 / t[2], t[4] * 0.01 / t[3], t[6] * 0.01);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks_m16), z, sizeof(z));
+    }
+#endif
     return AY_OK;
 }

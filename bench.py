@@ -228,7 +228,8 @@ def main():
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": "ay::conv_bf16_ring_kernel<3,1,128,2,4,16,32,1,2,res|nores> (3x3 s1, 128 ch x 512 px tile, persistent LDS-DMA ring)",
+                "kernel": "ay::conv3x3_m16_ring_kernel<res|nores> (3x3 s1, 128 ch x 512 px tile, v_mfma_f32_16x16x32_bf16, persistent LDS-DMA ring; "
+                          "AY_M16=0: ay::conv_bf16_ring_kernel<3,1,128,2,4,16,32,1,2,...> on 32x32x16)",
                 "launches_per_step": launches // a.steps, "avg_launch_ms": round(ms / launches, 4),
                 "flops_per_launch": fam_flops / (launches // a.steps), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
             }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# same-box A/B of library builds: scripts/dbg/ab_bench.sh name1 name2 ...  (ab/lib_<name>.so), two interleaved rounds of bench.py
+L=amyloid_yolo_paper_amd/libamyloid_yolo_hip.so
+cp $L ab/lib_keep.so
+for rep in 1 2; do
+  for v in "$@"; do
+    cp ab/lib_$v.so $L
+    timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{})
+print('$v', d['ms_per_step'], 'ms/step', d['value'], 'tiles/s  family', r.get('avg_launch_ms'), 'ms', r.get('frac'))"
+  done
+done
+cp ab/lib_keep.so $L
