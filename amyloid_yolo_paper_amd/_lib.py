@@ -58,6 +58,7 @@ _SIGS = {
     "ay_bn_train_fwd_f32": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ay_bn_train_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ay_bias_grad_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ay_bias_grad_f32_acc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_conv_dgrad_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     "ay_conv_wgrad_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "ay_add_f32": (_I, [_P, _P, _P, _SZ, _P]),
@@ -86,11 +87,13 @@ _SIGS = {
     "ay_adam_flat": (_I, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _F, _P]),
     "ay_bn_train_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_bn_train_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_bn_train_bwd_bf16_acc": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ay_accumulate_bf16": (_I, [_P, _P, _SZ, _P]),
     "ay_slice_accumulate_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ay_zero_insert_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ay_pack_dgrad_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_conv_wgrad_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "ay_conv_wgrad_bf16_acc": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

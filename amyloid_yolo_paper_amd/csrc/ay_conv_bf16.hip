@@ -813,7 +813,9 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             return launch<3, 1, 128, 2, 4, 16, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 128 == 0) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        return launch<3, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        // 32 output channels (the stem and the data gradients that end in it during training: HBM-bound, 1.4 ms per launch at
+        // B=32 / 1024^2 on the register-staged kernel): the ring kernel with a 32-channel tile, one 32x32 block per wave
+        return launch<3, 1, 32, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
     }
     if (d->ksize == 3 && d->stride == 2) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
@@ -832,7 +834,7 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
             return launch_ring1x1<256, 4, 2, false>(d, nullptr, 0, src, w_packed, scale, shift, out, st);
         if (cp % 128 == 0) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
         if (cp % 64 == 0) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        return launch<1, 1, 32, 1, 4, 8, 32, 4, false>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<1, 1, 32, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
     }
     if (d->out_f32) return launch<1, 1, 32, 1, 4, 8, 32, 1, true>(d, src, w_packed, scale, shift, residual, out, st);
     return launch<1, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);

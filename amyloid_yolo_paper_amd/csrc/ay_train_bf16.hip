@@ -19,15 +19,19 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
 
-// ---- per-channel sums over (B,H,W) of a blocked bf16 tensor: sums[c] += sum z, sums[C + c] += sum z^2 (fp64 atomics)
-// grid (pixel chunks, planes, batch groups); one thread = one 16-byte unit (pixel, 8 channels) per step, its channel
-// parameters in registers; thread parity = channel half (all strides are even).  The four waves of a workgroup are
-// reduced through LDS first: one atomic per channel per workgroup (contended fp64 atomics were most of this kernel).
+// The four BatchNorm passes are HBM streams; each workgroup works inside ONE 16-channel plane of ONE image (grid.y = plane,
+// grid.x = image * chunks + chunk), so a thread keeps the parameters of its 8 channels in registers (thread parity = channel
+// half: all strides are even), and every thread has UNROLL independent 16-byte loads in flight per operand (with one load per
+// loop iteration the passes ran at ~2 TB/s: 41 % of the 1024^2 training step, profiles/r01_train_b16_s1024_kernel_stats.csv).
+constexpr int BN_UNROLL = 4;
+
+// ---- per-channel sums over (B,H,W) of a blocked bf16 tensor: sums[c] += sum z, sums[C + c] += sum z^2 (fp64 atomics, one per
+// channel and workgroup after a reduction through LDS); BWD: a = dy, zt = z: sums = (sum dpre, sum dpre * xhat)
 template <bool BWD>
 __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ a, const uint4* __restrict__ zt,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
-                                                      double* __restrict__ sums, int C, int HW, int B) {
+                                                      double* __restrict__ sums, int C, int HW, int chunks) {
     __shared__ float red[4][2][16];
     const int plane = blockIdx.y;
     const int CP = gridDim.y;
@@ -46,21 +50,34 @@ __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ 
         }
     }
     const int units = HW * 2;
-    const int stride = gridDim.x * 256;
-    for (int b = blockIdx.z; b < B; b += gridDim.z) {
-        const size_t base = ((size_t)b * CP + plane) * units;
-        for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += stride) {
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int stride = chunks * 256;
+    const size_t base = ((size_t)b * CP + plane) * units;
+    for (int u0 = chunk * 256 + threadIdx.x; u0 < units; u0 += stride * BN_UNROLL) {
+        uint4 va[BN_UNROLL], vz[BN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BN_UNROLL; ++k) {
+            const int u = u0 + k * stride;
+            va[k] = make_uint4(0, 0, 0, 0);
+            vz[k] = make_uint4(0, 0, 0, 0);
+            if (u < units) {
+                va[k] = a[base + u];
+                if (BWD) vz[k] = zt[base + u];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BN_UNROLL; ++k) {
             float f[8];
-            unpack8(a[base + u], f);
+            unpack8(va[k], f);
             if (!BWD) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     s1[j] += f[j];
                     s2[j] += f[j] * f[j];
                 }
-            } else {  // a = dy, zt = z: s1 = sum dpre, s2 = sum dpre * xhat
+            } else {  // a zero dy (the fill of an out-of-range unit) adds nothing to either sum
                 float z[8];
-                unpack8(zt[base + u], z);
+                unpack8(vz[k], z);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xh = (z[j] - mu[j]) * is[j];
@@ -111,20 +128,19 @@ __global__ void bn_finalize_fwd_kernel(const double* sums, double n, float eps, 
     running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
-__global__ void bn_finalize_bwd_kernel(const double* sums, float* dgamma, float* dbeta, int C) {
+// accumulate != 0: the parameter gradients are ADDED to dgamma / dbeta (gradient accumulation over batches, train.py:116-119)
+__global__ void bn_finalize_bwd_kernel(const double* sums, float* dgamma, float* dbeta, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    dbeta[c] = (float)sums[c];
-    dgamma[c] = (float)sums[C + c];
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
 }
 
 // y = bf16( leaky(gamma * (z - mean) * invstd + beta) [+ skip] )
-// grid (pixel chunks, planes, batch): a thread keeps the parameters of its 8 channels in registers (they used to be 32
-// scalar loads per 16-byte unit) and walks pixels with an even stride.
 __global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int leaky, const uint4* __restrict__ skip,
-                                                       uint4* __restrict__ y, int C, int CP, int HW) {
+                                                       uint4* __restrict__ y, int C, int CP, int HW, int chunks) {
     const int plane = blockIdx.y;
     const int half = threadIdx.x & 1;
     const int c0 = plane * 16 + half * 8;
@@ -138,19 +154,36 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__
         be[j] = beta[c];
     }
     const int units = HW * 2;
-    const size_t base = ((size_t)blockIdx.z * CP + plane) * units;
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
-        float f[8], s[8];
-        unpack8(z[base + u], f);
-        if (skip) unpack8(skip[base + u], s);
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int stride = chunks * 256;
+    const size_t base = ((size_t)b * CP + plane) * units;
+    for (int u0 = chunk * 256 + threadIdx.x; u0 < units; u0 += stride * BN_UNROLL) {
+        uint4 vz[BN_UNROLL], vs[BN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = (f[j] - mu[j]) * is[j] * ga[j] + be[j];
-            if (leaky) v = v > 0.f ? v : 0.1f * v;
-            if (skip) v += s[j];
-            f[j] = c0 + j < C ? v : 0.f;
+        for (int k = 0; k < BN_UNROLL; ++k) {
+            const int u = u0 + k * stride;
+            vz[k] = make_uint4(0, 0, 0, 0);
+            vs[k] = make_uint4(0, 0, 0, 0);
+            if (u < units) {
+                vz[k] = z[base + u];
+                if (skip) vs[k] = skip[base + u];
+            }
         }
-        y[base + u] = pack8(f);
+#pragma unroll
+        for (int k = 0; k < BN_UNROLL; ++k) {
+            const int u = u0 + k * stride;
+            float f[8], sk[8];
+            unpack8(vz[k], f);
+            unpack8(vs[k], sk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (f[j] - mu[j]) * is[j] * ga[j] + be[j];
+                if (leaky) v = v > 0.f ? v : 0.1f * v;
+                if (skip) v += sk[j];
+                f[j] = c0 + j < C ? v : 0.f;
+            }
+            if (u < units) y[base + u] = pack8(f);
+        }
     }
 }
 
@@ -159,7 +192,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
                                                            const double* __restrict__ sums, float n, uint4* __restrict__ dz, int C, int CP,
-                                                           int HW) {
+                                                           int HW, int chunks) {
     const int plane = blockIdx.y;
     const int half = threadIdx.x & 1;
     const int c0 = plane * 16 + half * 8;
@@ -175,21 +208,38 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restri
         sg[j] = (float)sums[C + c];
     }
     const int units = HW * 2;
-    const size_t base = ((size_t)blockIdx.z * CP + plane) * units;
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
-        float d[8], zz[8];
-        unpack8(dy[base + u], d);
-        unpack8(z[base + u], zz);
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int stride = chunks * 256;
+    const size_t base = ((size_t)b * CP + plane) * units;
+    for (int u0 = chunk * 256 + threadIdx.x; u0 < units; u0 += stride * BN_UNROLL) {
+        uint4 vd[BN_UNROLL], vz[BN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (zz[j] - mu[j]) * is[j];
-            const float pre = xh * ga[j] + be[j];
-            const float dp = (leaky && !(pre > 0.f)) ? 0.1f * d[j] : d[j];
-            const float k = ga[j] * is[j] / n;
-            const float v = k * (n * dp - sb[j] - xh * sg[j]);
-            d[j] = c0 + j < C ? v : 0.f;
+        for (int k = 0; k < BN_UNROLL; ++k) {
+            const int u = u0 + k * stride;
+            vd[k] = make_uint4(0, 0, 0, 0);
+            vz[k] = make_uint4(0, 0, 0, 0);
+            if (u < units) {
+                vd[k] = dy[base + u];
+                vz[k] = z[base + u];
+            }
         }
-        dz[base + u] = pack8(d);
+#pragma unroll
+        for (int k = 0; k < BN_UNROLL; ++k) {
+            const int u = u0 + k * stride;
+            float d[8], zz[8];
+            unpack8(vd[k], d);
+            unpack8(vz[k], zz);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (zz[j] - mu[j]) * is[j];
+                const float pre = xh * ga[j] + be[j];
+                const float dp = (leaky && !(pre > 0.f)) ? 0.1f * d[j] : d[j];
+                const float k2 = ga[j] * is[j] / n;
+                const float v = k2 * (n * dp - sb[j] - xh * sg[j]);
+                d[j] = c0 + j < C ? v : 0.f;
+            }
+            if (u < units) dz[base + u] = pack8(d);
+        }
     }
 }
 
@@ -276,20 +326,14 @@ __global__ void pack_dgrad_weights_kernel(const float* __restrict__ w, uint16_t*
     }
 }
 
-// grids of the BatchNorm passes: x = chunks of a plane's 2*HW units (>= 4 units per thread where the plane allows),
-// z = batch (apply passes) or up to 4 batch groups (sums: gx * bz workgroups issue one atomic per channel each)
-struct BnGrid {
-    int gx_sums, gx_apply, bz;
-};
-static inline BnGrid bn_grid(int batch, int HW) {
+// chunks of one (image, plane) slice: every thread gets about two rounds of BN_UNROLL units where the plane allows, and the whole
+// grid stays below ~16k workgroups (each sums workgroup ends with one fp64 atomic per channel)
+static inline int bn_chunks(int batch, int planes, int HW) {
     const int units = HW * 2;
-    int gx = (units + 4 * 256 - 1) / (4 * 256);
-    if (gx < 1) gx = 1;
-    BnGrid g;
-    g.gx_apply = gx > 64 ? 64 : gx;
-    g.gx_sums = gx > 32 ? 32 : gx;
-    g.bz = batch < 4 ? batch : 4;
-    return g;
+    int c = (units + 256 * BN_UNROLL * 2 - 1) / (256 * BN_UNROLL * 2);
+    const long long cap = 16384ll / ((long long)batch * planes > 0 ? (long long)batch * planes : 1);
+    if (c > cap) c = (int)cap;
+    return c < 1 ? 1 : c;
 }
 
 static inline unsigned gridu(size_t units) {
@@ -312,22 +356,22 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    const BnGrid g = bn_grid(batch, HW);
-    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(g.gx_sums, CP, g.bz), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, 0, sums_ws, channels, HW, batch);
+    const int ch = bn_chunks(batch, CP, HW);
+    hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, 0, sums_ws, channels, HW, ch);
     AY_CHECK_LAUNCH("bn_sums_kernel");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, (double)batch * HW, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, channels);
     AY_CHECK_LAUNCH("bn_finalize_fwd_kernel");
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.gx_apply, CP, batch), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta,
-                       leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta,
+                       leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW, ch);
     AY_CHECK_LAUNCH("bn_apply_kernel");
     return AY_OK;
 }
 
-extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
-                                    const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, int batch,
-                                    int channels, int h, int w, ay_stream_t stream) {
+extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
+                                        int accumulate, int batch, int channels, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(dy && z && gamma && beta && save_mean && save_invstd && dz && dgamma && dbeta && sums_ws, "ay_bn_train_bwd_bf16: null");
     hipStream_t st = S(stream);
     const int CP = (channels + 15) / 16, HW = h * w;
@@ -335,16 +379,23 @@ extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* 
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
-    const BnGrid g = bn_grid(batch, HW);
-    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(g.gx_sums, CP, g.bz), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
-                       gamma, beta, leaky, sums_ws, channels, HW, batch);
+    const int ch = bn_chunks(batch, CP, HW);
+    hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
+                       gamma, beta, leaky, sums_ws, channels, HW, ch);
     AY_CHECK_LAUNCH("bn_sums_kernel<bwd>");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels, accumulate);
     AY_CHECK_LAUNCH("bn_finalize_bwd_kernel");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.gx_apply, CP, batch), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean,
-                       save_invstd, gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean,
+                       save_invstd, gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW, ch);
     AY_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return AY_OK;
+}
+
+extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, int batch,
+                                    int channels, int h, int w, ay_stream_t stream) {
+    return ay_bn_train_bwd_bf16_acc(dy, z, gamma, beta, save_mean, save_invstd, leaky, dz, dgamma, dbeta, sums_ws, 0, batch, channels, h, w,
+                                    stream);
 }
 
 extern "C" int ay_accumulate_bf16(void* dst, const void* src, size_t n_elems, ay_stream_t stream) {

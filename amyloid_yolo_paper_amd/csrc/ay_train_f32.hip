@@ -107,14 +107,19 @@ __global__ void __launch_bounds__(256) bn_train_bwd_kernel(const float* __restri
 }
 
 // bias-only (linear head) backward: db[c] = sum dz
+// db[c] (+)= sum over batch and pixels of dz[b][c][:]; grid (channels, chunks): a chunk is a contiguous range of one channel's
+// B*HW values, summed in fixed order and added with ONE atomic (the db entries are zeroed first unless `accumulate`); with one
+// workgroup per channel the 24-channel head gradients of a 1024^2 batch took 0.36 ms each
 __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db, int B, int C, int HW) {
     __shared__ float sm[4];
     const int c = blockIdx.x;
     const long long n = (long long)B * HW;
+    const long long per = (n + gridDim.y - 1) / gridDim.y;
+    const long long lo = per * blockIdx.y, hi = lo + per < n ? lo + per : n;
     float s = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 256) s += dz[((i / HW) * C + c) * (long long)HW + i % HW];
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) s += dz[((i / HW) * C + c) * (long long)HW + i % HW];
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) db[c] = s;
+    if (threadIdx.x == 0) atomicAdd(&db[c], s);
 }
 
 // ------------------------------------------------------------------------------------------ conv backward
@@ -503,11 +508,29 @@ extern "C" int ay_bn_train_bwd_f32(const float* dy, const float* y, const float*
     return AY_OK;
 }
 
-extern "C" int ay_bias_grad_f32(const float* dz, float* dbias, int batch, int channels, int hw, ay_stream_t stream) {
+static int bias_grad_launch(const float* dz, float* dbias, int accumulate, bool chunked, int batch, int channels, int hw, ay_stream_t stream) {
     AY_CHECK_ARG(dz && dbias, "ay_bias_grad_f32: null");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(channels), dim3(256), 0, S(stream), dz, dbias, batch, channels, hw);
+    if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * channels, S(stream)) != hipSuccess) {
+        set_error("ay_bias_grad_f32: memset failed");
+        return AY_ERR_LAUNCH;
+    }
+    const long long n = (long long)batch * hw;
+    int chunks = chunked ? (int)((n + 16383) / 16384) : 1;  // one chunk: one fixed-order sum per channel (reproducible)
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(channels, chunks), dim3(256), 0, S(stream), dz, dbias, batch, channels, hw);
     AY_CHECK_LAUNCH("bias_grad_kernel");
     return AY_OK;
+}
+
+// the bf16 training step: chunked (up to 256 partial sums per channel, combined by atomics)
+extern "C" int ay_bias_grad_f32_acc(const float* dz, float* dbias, int accumulate, int batch, int channels, int hw, ay_stream_t stream) {
+    return bias_grad_launch(dz, dbias, accumulate, true, batch, channels, hw, stream);
+}
+
+// the fp32 parity path: one workgroup per channel, fixed summation order
+extern "C" int ay_bias_grad_f32(const float* dz, float* dbias, int batch, int channels, int hw, ay_stream_t stream) {
+    return bias_grad_launch(dz, dbias, 0, false, batch, channels, hw, stream);
 }
 
 extern "C" int ay_conv_dgrad_f32(const ay_conv_desc* d, const float* dz, const float* w_oihw, float* dx, int accumulate,

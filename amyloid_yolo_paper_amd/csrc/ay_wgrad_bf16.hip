@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
 }  // namespace ay
 
 extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream) {
+    return ay_conv_wgrad_bf16_acc(d, x_blocked, dz_blocked, dw_oihw, 0, stream);
+}
+
+extern "C" int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
+                                      ay_stream_t stream) {
     using namespace ay;
     AY_CHECK_ARG(d && x_blocked && dz_blocked && dw_oihw, "ay_conv_wgrad_bf16: null");
     // cin need not be a multiple of 16: x is read as ceil(cin/16) planes (pad channels must be zero), dW rows ci >= cin are skipped
@@ -231,7 +236,8 @@ extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, 
     if (ks > total) ks = total;
     if (ks > 65535) ks = 65535;
     if (ks < 1) ks = 1;
-    if (hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ksize * d->ksize, st) != hipSuccess) {
+    // the kernel ADDS its split-K partial sums (fp32 atomics): accumulate = 0 starts from zero, 1 from what dw holds
+    if (!accumulate && hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ksize * d->ksize, st) != hipSuccess) {
         set_error("ay_conv_wgrad_bf16: memset failed");
         return AY_ERR_LAUNCH;
     }

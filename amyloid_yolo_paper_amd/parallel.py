@@ -9,9 +9,14 @@
   (`models.py:43`), and rank 0's running statistics are the ones checkpointed.
 """
 import os
+import re
 
 import torch
 import torch.distributed as dist
+
+# bumped by every optimiser step that changes the parameters behind torch's back (FlatAdam writes through raw pointers, which
+# does not touch Tensor._version): the training engine re-packs its filter images when this or a parameter version changes
+WEIGHT_EPOCH = [0]
 
 
 def dist_env():
@@ -37,6 +42,17 @@ def init_distributed(backend=None):
 def shard_indices(n_items, rank, world):
     """round-robin shard of tile indices: rank r takes r, r+world, ... (every tile exactly once, sizes differ by <= 1)"""
     return list(range(rank, n_items, world))
+
+
+def shard_indices_equal(n_items, rank, world):
+    """training shard: as ``shard_indices`` but every rank gets ceil(n/world) indices (the tail wraps around to the first tiles,
+    like ``DistributedSampler``): ranks then run the SAME number of batches, so optimiser steps, accumulation boundaries and
+    collectives line up on every rank (with shards of unequal length the ranks' ``batches_done`` drift apart and their
+    all-reduces pair up across different steps, or hang at the tail)."""
+    if n_items == 0:
+        return []
+    per = (n_items + world - 1) // world
+    return [(rank + k * world) % n_items for k in range(per)]
 
 
 class FlatGradReducer:
@@ -73,6 +89,41 @@ class FlatGradReducer:
         if start < total:
             self.buckets.append((start, total))
 
+    # ---- overlap with the backward walk --------------------------------------------------------------------------------
+    def attach(self, model):
+        """Let the bf16 training engine report finished layers (``model._grad_ready(layer)``, deepest layer first): a bucket's
+        all-reduce is issued as soon as the gradients of its shallowest layer have been enqueued -- ``torch.distributed``
+        orders the collective behind the work already on the current stream and runs it on its own stream, so it overlaps
+        the backward of the layers below (between ``loss.backward()`` and ``optimizer.step()``, train.py:114-118)."""
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        assert len(names) == len(self.params)
+        layer_of = [int(re.match(r"module_list\.(\d+)\.", n).group(1)) for n in names]
+        self.bucket_first_layer = []
+        for (a, b) in self.buckets:
+            layers = [l for l, (o, n) in zip(layer_of, self.offsets) if o < b and o + n > a]
+            self.bucket_first_layer.append(min(layers))
+        self._armed = False
+        self._handles = {}
+        model._grad_ready = self.layer_done
+        return self
+
+    def begin(self):
+        """arm the hooks for the next backward (the one that ends an accumulation window)"""
+        self._armed = self._active()
+        self._handles = {}
+
+    def layer_done(self, layer):
+        """layer < 0: the backward walk is over"""
+        if not getattr(self, "_armed", False):
+            return
+        for k in range(len(self.buckets) - 1, -1, -1):
+            if k not in self._handles and (layer < 0 or layer <= self.bucket_first_layer[k]):
+                a, b = self.buckets[k]
+                self._handles[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _active(self):
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or bool(os.environ.get("AY_FORCE_DIST")))
+
     def views_intact(self):
         return all(p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * o for p, (o, _) in zip(self.params, self.offsets))
 
@@ -81,12 +132,14 @@ class FlatGradReducer:
 
     def all_reduce(self, average=True):
         """sum over ranks (bucketed, async, reverse order), then 1/world; returns the number of bytes exchanged per rank"""
-        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not os.environ.get("AY_FORCE_DIST")):
+        if not self._active():
             return 0  # (AY_FORCE_DIST: run the collectives with one rank too -- rehearsal of the N>1 path on a 1-GPU box)
         assert self.views_intact(), "parameter .grad no longer aliases the flat buffer (zero_grad(set_to_none=True)?)"
         world = dist.get_world_size(self.group)
-        handles = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for (a, b) in reversed(self.buckets)]
+        issued = self._handles if getattr(self, "_armed", False) else {}   # buckets already in flight (begin() + engine hooks)
+        handles = [issued[k] if k in issued else dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for k, (a, b) in reversed(list(enumerate(self.buckets)))]
+        self._armed, self._handles = False, {}
         for h in handles:
             h.wait()
         if average:
@@ -123,6 +176,7 @@ class FlatAdam:
         import ctypes as C
         from . import _lib
         self.step_count += 1
+        WEIGHT_EPOCH[0] += 1
         _lib.check(_lib.lib().ay_adam_flat(_lib.ptr(self.flat), _lib.ptr(self.red.flat), _lib.ptr(self.m), _lib.ptr(self.v), self.flat.numel(),
                                             C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                             self.step_count, C.c_float(grad_scale), _lib.stream_ptr()), "ay_adam_flat")

@@ -16,7 +16,7 @@ from torch.utils.data import DataLoader, Subset
 
 from .datasets import ListDataset
 from .models import Darknet
-from .parallel import FlatGradReducer, broadcast_parameters, init_distributed, shard_indices
+from .parallel import FlatAdam, FlatGradReducer, broadcast_parameters, init_distributed, shard_indices_equal
 from .parse_config import parse_data_config
 from .train_engine import METRIC_KEYS
 from .utils import load_classes, weights_init_normal
@@ -53,39 +53,57 @@ def train(epochs=100, batch_size=8, gradient_accumulations=2, model_def="config/
             model.load_darknet_weights(pretrained_weights)
     broadcast_parameters(model)
     dataset = ListDataset(cfg["train"], multiscale=multiscale_training, img_size=img_size)
-    data = Subset(dataset, shard_indices(len(dataset), rank, world)) if world > 1 else dataset
+    # every rank gets the same number of tiles (the tail wraps around), hence the same number of batches: optimiser steps,
+    # accumulation boundaries and collectives line up on all ranks
+    data = Subset(dataset, shard_indices_equal(len(dataset), rank, world)) if world > 1 else dataset
     loader = DataLoader(data, batch_size=batch_size, shuffle=True, num_workers=n_cpu, pin_memory=True, collate_fn=dataset.collate_fn)
-    optimizer = torch.optim.Adam(model.parameters())
-    reducer = FlatGradReducer(model.parameters(), n_buckets=4)
+    # one exchange per optimiser step over a flat gradient buffer, overlapped with the backward on the bf16 path; the update is
+    # torch.optim.Adam's (train.py:81: default hyper-parameters, no schedule) as one kernel over the flat buffers -- the step
+    # bench.py --mode train times
+    reducer = FlatGradReducer(model.parameters(), n_buckets=4).attach(model)
+    optimizer = FlatAdam(reducer)
+    ctrl = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=6))   # host-side barrier around rank 0's evaluation
     history = []
     for epoch in range(epochs):
         model.train()
         t0 = time.time()
         for batch_i, (_, imgs, targets) in enumerate(loader):
-            batches_done = len(loader) * epoch + batch_i
+            batches_done = len(loader) * epoch + batch_i          # the same on every rank (equal shards)
+            step_now = batches_done % gradient_accumulations == 0  # train.py:116: after batch 0, 2, 4, ... gradients summed
+            if step_now:
+                reducer.begin()                                    # buckets go out while the backward is still running
             loss, outputs = model(imgs.to(dev), targets.to(dev))
             loss.backward()
-            if batches_done % gradient_accumulations == 0:
-                reducer.all_reduce()           # the one exchange step of data parallelism
-                optimizer.step()
-                optimizer.zero_grad(set_to_none=False)
+            if step_now:
+                reducer.all_reduce(average=False)      # the one exchange step of data parallelism (waits for the buckets)
+                optimizer.step(grad_scale=1.0 / world)
+                reducer.zero()
             model.seen += imgs.size(0) * world
             history.append(float(loss.item()))
             if rank == 0 and (verbose or batch_i % 10 == 0):
                 print(format_metrics(model, epoch, epochs, batch_i, len(loader)) + f"\nTotal loss {history[-1]:.4f}", flush=True)
             if max_batches is not None and batches_done + 1 >= max_batches:
                 break
-        if rank == 0 and epoch % evaluation_interval == 0 and "valid" in cfg and os.path.exists(cfg["valid"]):
-            from .test import evaluate
-            res = evaluate(model, cfg["valid"], 0.5, 0.5, 0.5, img_size, 8)
-            if res is not None:
-                precision, recall, AP, f1, ap_class = res
-                for i, c in enumerate(ap_class):
-                    print(f"+ Class '{c}' ({class_names[c]}) - AP: {AP[i]:.5f}")
-                print(f"---- mAP {AP.mean():.5f}   epoch time {time.time() - t0:.1f}s")
+        if epoch % evaluation_interval == 0 and "valid" in cfg and os.path.exists(cfg["valid"]):
+            if rank == 0:
+                from .test import evaluate
+                res = evaluate(model, cfg["valid"], 0.5, 0.5, 0.5, img_size, 8)
+                if res is not None:
+                    precision, recall, AP, f1, ap_class = res
+                    for i, c in enumerate(ap_class):
+                        print(f"+ Class '{c}' ({class_names[c]}) - AP: {AP[i]:.5f}")
+                    print(f"---- mAP {AP.mean():.5f}   epoch time {time.time() - t0:.1f}s")
+            if ctrl is not None:
+                import torch.distributed as dist
+                dist.barrier(group=ctrl)   # the other ranks wait on the host, not inside the next RCCL collective
         if rank == 0 and epoch % checkpoint_interval == 0:
             os.makedirs(checkpoint_dir, exist_ok=True)
-            torch.save(model.state_dict(), os.path.join(checkpoint_dir, "yolov3_ckpt_%d.pth" % epoch))
+            # (parameters are views of the optimiser's flat buffer: save plain copies, the reference's .pth schema)
+            torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(checkpoint_dir, "yolov3_ckpt_%d.pth" % epoch))
         if max_batches is not None and len(history) >= max_batches:
             break
     return model, history

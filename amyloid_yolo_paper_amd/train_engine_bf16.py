@@ -6,7 +6,16 @@
   into the apply pass; its backward recomputes the pre-activation from the saved raw output;
 * the stem runs through the same kernels (the fp32 image becomes one zero-padded 16-channel bf16 plane); the YOLO loss
   stays on the fp32 kernel;
-* parameter gradients are fp32 (``.grad`` of the fp32 master parameters), activations / activation gradients bf16.
+* parameter gradients are fp32 and are ADDED straight into ``p.grad`` by the kernels (``*_acc`` entry points): with
+  ``parallel.FlatGradReducer`` those are views of one flat buffer, so a step needs neither per-layer gradient temporaries
+  nor autograd's accumulation pass, and ``model._grad_ready(layer)`` (set by the reducer) can start a bucket's all-reduce
+  while the backward of the shallower layers is still running (reference: ``train.py:113-119``).
+
+Memory: everything the step touches lives in a per-(batch, size) context that persists across steps -- the saved forward
+tensors (raw output z and activation y of every layer: the backward needs both), small per-layer statistics, and a
+shape-keyed pool for the backward's gradient tensors, which are handed back as soon as their consumer has been issued
+(one stream: issue order is execution order).  Filters are packed for the forward and the data-gradient kernels once per
+optimiser step (when a parameter's version or ``parallel.WEIGHT_EPOCH`` changes), not once per forward.
 """
 import ctypes as C
 
@@ -22,12 +31,107 @@ def _pad(v, m):
 
 
 class _State:
+    """what one forward leaves for its backward (tests read .conv[i]["z"], .val[i])"""
+
     def __init__(self):
         self.val = {}
         self.conv = {}
         self.dhead = {}
         self.route = {}
         self.B = self.S = 0
+        self.ctx = None
+
+
+class _Pool:
+    """shape-keyed free lists of device tensors (gradient tensors of the backward walk)"""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.free = {}
+        self.bytes = 0
+
+    def get(self, shape, dtype=torch.bfloat16):
+        key = (tuple(shape), dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        t = torch.empty(*shape, device=self.dev, dtype=dtype)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def put(self, t):
+        self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
+class _Ctx:
+    """persistent buffers of one (batch, size) training shape"""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.buf = {}
+        self.pool = _Pool(dev)
+        self.packed = {}
+        self.packed_sig = None
+
+    def get(self, key, shape, dtype=torch.bfloat16, zero=False):
+        t = self.buf.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
+            self.buf[key] = t
+        return t
+
+    def bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.buf.values()) + self.pool.bytes
+
+
+def _weights_signature(model):
+    from . import parallel
+    ps = list(model.parameters())
+    return (parallel.WEIGHT_EPOCH[0], sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr())
+
+
+def _pack_weights(model, ctx):
+    """forward and data-gradient filter images of every convolution, once per optimiser step"""
+    sig = _weights_signature(model)
+    if ctx.packed_sig == sig:
+        return ctx.packed
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    graph = model._graph
+    for i, e in enumerate(graph):
+        if e["type"] != "convolutional":
+            continue
+        conv = model.module_list[i][0]
+        cout, cin, k = e["cout"], e["cin"], e["k"]
+        w = conv.weight.detach()
+        rec = ctx.packed.setdefault(i, {})
+        cin_eff = cin
+        if e["src"] < 0:  # stem: filters get zero input channels 3..15
+            w16 = ctx.get(("w16", i), (cout, 16, k, k), torch.float32, zero=True)
+            w16[:, :cin].copy_(w)
+            w, cin_eff = w16, 16
+        cpad = _pad(cout, 32)
+        nbytes = L.ay_packed_weight_bytes(cpad, cin_eff, k)
+        fwd = ctx.get(("pk", i), (nbytes,), torch.uint8)
+        check(L.ay_pack_conv_weights_bf16(ptr(w), ptr(fwd), cout, cpad, cin_eff, k, st), "ay_pack_conv_weights_bf16")
+        rec.update(fwd=fwd, cpad=cpad, cin_eff=cin_eff)
+        if e["src"] >= 0:
+            cin_pad = _pad(cin, 32)
+            dg = ctx.get(("pkd", i), ((cpad // 16) * k * k * 2 * cin_pad * 8 * 2,), torch.uint8, zero=True)  # rows of the pad planes stay zero
+            check(L.ay_pack_dgrad_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cin, cin_pad, k, st), "ay_pack_dgrad_weights_bf16")
+            rec.update(dgrad=dg, cin_pad=cin_pad)
+    ctx.packed_sig = sig
+    return ctx.packed
+
+
+def _context(model, B, S, dev):
+    ctxs = model.__dict__.setdefault("_train_ctx", {})
+    key = (B, S, str(dev))
+    if key not in ctxs:
+        if len(ctxs) >= 2:  # multiscale training walks through sizes: keep the two most recent shapes
+            ctxs.pop(next(iter(ctxs)))
+        ctxs[key] = _Ctx(dev)
+    return ctxs[key]
 
 
 def train_forward_bf16(model, x, targets):
@@ -39,26 +143,28 @@ def train_forward_bf16(model, x, targets):
     assert S == S2 and S % 32 == 0
     assert model.training, "the bf16 training path implements train-mode BatchNorm only"
     graph = model._graph
+    ctx = _context(model, B, S, dev)
+    packed = _pack_weights(model, ctx)
     stt = _State()
-    stt.B, stt.S = B, S
+    stt.B, stt.S, stt.ctx = B, S, ctx
     val = stt.val
     Ccls = model.yolo_layers[0].num_classes
     N = model.num_boxes(S)
-    out = torch.empty(B, N, 5 + Ccls, device=dev, dtype=torch.float32)
+    out = ctx.get("out", (B, N, 5 + Ccls), torch.float32)
     tg = None if targets is None else targets.detach().to(device=dev, dtype=torch.float32).contiguous()
 
     def size_of(i):
         return S >> graph[i]["log2_down"] if i >= 0 else S
 
-    def blocked(c, h, dtype=torch.bfloat16, pad=16):
-        return torch.empty(B, _pad(c, pad) // 16, h, h, 16, device=dev, dtype=dtype)
+    def blocked(key, c, h, dtype=torch.bfloat16, pad=16):
+        return ctx.get(key, (B, _pad(c, pad) // 16, h, h, 16), dtype)
 
     def resolve(i):
         v = val[i]
         if isinstance(v, tuple):
             src = resolve(v[1])
             c, h = graph[i]["channels"], size_of(i)
-            o = blocked(c, h)
+            o = blocked(("up", i), c, h)
             check(L.ay_concat_upsample_bf16(ptr(src), c, 1, None, 0, ptr(o), B, h, h, st), "ay_concat_upsample_bf16")
             val[i] = o
             return o
@@ -66,8 +172,6 @@ def train_forward_bf16(model, x, targets):
 
     row = 0
     sums_all = []
-    n_layers = len(graph)
-    skip_next = False
     for i, e in enumerate(graph):
         t = e["type"]
         if t == "convolutional":
@@ -75,50 +179,45 @@ def train_forward_bf16(model, x, targets):
             conv = m[0]
             hin, hout = size_of(e["src"]), size_of(i)
             cout, cin, k = e["cout"], e["cin"], e["k"]
-            w = conv.weight.detach()
+            pk = packed[i]
+            cpad, cin_eff = pk["cpad"], pk["cin_eff"]
             if e["src"] < 0:
-                # ---- stem: the fp32 image becomes ONE zero-padded 16-channel bf16 plane, the filters get zero input
-                # channels 3..15, and the layer runs through the same MFMA kernels as every other layer
+                # ---- stem: the fp32 image becomes ONE zero-padded 16-channel bf16 plane and the layer runs through the
+                # same MFMA kernels as every other layer
                 assert e["bn"] and cin <= 16
-                xb = blocked(16, hin)
-                check(L.ay_nchw_f32_to_blocked_bf16(ptr(x), ptr(xb), B, cin, hin, hin, st), "ay_nchw_f32_to_blocked_bf16")
-                w16 = torch.zeros(cout, 16, k, k, device=dev, dtype=torch.float32)
-                w16[:, :cin] = w
-                src, stem_w, cin_eff = xb, w16, 16
+                src = blocked("xb", 16, hin)
+                check(L.ay_nchw_f32_to_blocked_bf16(ptr(x), ptr(src), B, cin, hin, hin, st), "ay_nchw_f32_to_blocked_bf16")
             else:
-                src, stem_w, cin_eff = resolve(e["src"]), None, cin
-            cpad = _pad(cout, 32)
+                src = resolve(e["src"])
             is_head = not e["bn"]
-            packed = torch.empty(L.ay_packed_weight_bytes(cpad, cin_eff, k), device=dev, dtype=torch.uint8)
-            check(L.ay_pack_conv_weights_bf16(ptr(w if stem_w is None else stem_w), ptr(packed), cout, cpad, cin_eff, k, st), "ay_pack_conv_weights_bf16")
             ones, zeros = model._unit(cpad, dev)
             d = ConvDesc(B, cin_eff, cout, hin, hin, hout, hout, k, e["stride"], 0, int(is_head), cpad)
-            rec = dict(kind="head" if is_head else "bn", x=src, desc=d, w=w, src=e["src"], cpad=cpad, stem=stem_w is not None)
+            rec = dict(kind="head" if is_head else "bn", x=src, desc=d, src=e["src"], cpad=cpad, stem=e["src"] < 0)
             if is_head:
-                shift = torch.zeros(cpad, device=dev, dtype=torch.float32)
-                shift[:cout] = conv.bias.detach()
-                zb = blocked(cout, hout, torch.float32, 32)
-                check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(packed), ptr(ones), ptr(shift), None, ptr(zb), st), "ay_conv_fwd_bf16")
-                head = torch.empty(B, cout, hout, hout, device=dev, dtype=torch.float32)
+                shift = ctx.get(("shift", i), (cpad,), torch.float32, zero=True)
+                shift[:cout].copy_(conv.bias.detach())
+                zb = blocked(("zb", i), cout, hout, torch.float32, 32)
+                check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(shift), None, ptr(zb), st), "ay_conv_fwd_bf16")
+                head = ctx.get(("head", i), (B, cout, hout, hout), torch.float32)
                 check(L.ay_blocked_f32_to_nchw_f32(ptr(zb), ptr(head), B, cout, hout, hout, st), "ay_blocked_f32_to_nchw_f32")
-                rec["keep"] = (shift, packed)
                 stt.conv[i] = rec
                 val[i] = head
                 continue
             bn = m[1]
-            z = blocked(cout, hout, pad=32)
-            check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(packed), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
+            assert cout % 32 == 0, f"layer {i}: the bf16 training path needs BN layers with a multiple of 32 filters (got {cout})"
+            z = blocked(("z", i), cout, hout, pad=32)
+            check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
             fuse = e["fuse_into_shortcut"]
             skip = resolve(graph[i + 1]["b"]) if fuse else None
-            y = blocked(cout, hout, pad=32)
-            mean = torch.empty(cout, device=dev, dtype=torch.float32)
-            invstd = torch.empty(cout, device=dev, dtype=torch.float32)
-            ws = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+            y = blocked(("y", i), cout, hout, pad=32)
+            mean = ctx.get(("mean", i), (cout,), torch.float32)
+            invstd = ctx.get(("invstd", i), (cout,), torch.float32)
+            ws = ctx.get(("ws", i), (2 * cout,), torch.float64)
             check(L.ay_bn_train_fwd_bf16(ptr(z), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var),
                                          C.c_float(bn.momentum), C.c_float(bn.eps), int(e["leaky"]), ptr(skip), ptr(y), ptr(mean), ptr(invstd),
                                          ptr(ws), B, cout, hout, hout, st), "ay_bn_train_fwd_bf16")
             bn.num_batches_tracked += 1
-            rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, keep=(packed, ws))
+            rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, ws=ws)
             stt.conv[i] = rec
             if fuse:
                 val[i] = None          # never materialised: only the following shortcut uses it
@@ -142,7 +241,7 @@ def train_forward_bf16(model, x, targets):
                 up = isinstance(val[a], tuple)
                 base = val[a][1] if up else a
                 s1, s2 = resolve(base), resolve(b_)
-                o = blocked(e["channels"], h)
+                o = blocked(("route", i), e["channels"], h)
                 check(L.ay_concat_upsample_bf16(ptr(s1), graph[a]["channels"], int(up), ptr(s2), graph[b_]["channels"], ptr(o), B, h, h, st),
                       "ay_concat_upsample_bf16")
                 val[i] = o
@@ -156,8 +255,8 @@ def train_forward_bf16(model, x, targets):
             y.grid_size, y.img_dim = G, S
             row += y.num_anchors * G * G
             if tg is not None:
-                dhead = torch.empty_like(head)
-                sums = torch.empty(16, device=dev, dtype=torch.float32)
+                dhead = ctx.get(("dhead", i), tuple(head.shape), torch.float32)
+                sums = ctx.get(("sums", i), (16,), torch.float32)
                 nb = L.ay_yolo_loss_workspace_bytes(B, y.num_anchors, y.num_classes, G)
                 ws = _ws(model, nb, dev)
                 check((L.ay_yolo_loss_giou_fwd_bwd if getattr(model, 'box_loss', 'mse') == 'giou' else L.ay_yolo_loss_fwd_bwd)(ptr(head), ptr(tg), tg.shape[0], B, y.num_anchors, y.num_classes, G, S, anchors,
@@ -175,36 +274,57 @@ def train_forward_bf16(model, x, targets):
         lcls = allsums[:, 6] / (n_obj * Ccls)
         per_layer = lx + ly + lw + lh + lconf + lcls
         loss = per_layer.sum()
-        h = torch.stack([per_layer, lx, ly, lw, lh, lconf, lcls, 100.0 * allsums[:, 9] / n_obj, allsums[:, 13] / (n_obj + 1e-16),
-                         allsums[:, 14] / (n_obj + 1e-16), allsums[:, 13] / (allsums[:, 12] + 1e-16), allsums[:, 10] / n_obj,
-                         allsums[:, 11] / n_noobj], 1).cpu().numpy()
-        for li, (y, _, G) in enumerate(sums_all):
-            y.metrics = {k: float(h[li, j]) for j, k in enumerate(METRIC_KEYS[:-1])}
-            y.metrics["grid_size"] = G
+        if getattr(model, "collect_metrics", True):   # one host sync per step (the reference: 39, models.py:205-220)
+            h = torch.stack([per_layer, lx, ly, lw, lh, lconf, lcls, 100.0 * allsums[:, 9] / n_obj, allsums[:, 13] / (n_obj + 1e-16),
+                             allsums[:, 14] / (n_obj + 1e-16), allsums[:, 13] / (allsums[:, 12] + 1e-16), allsums[:, 10] / n_obj,
+                             allsums[:, 11] / n_noobj], 1).cpu().numpy()
+            for li, (y, _, G) in enumerate(sums_all):
+                y.metrics = {k: float(h[li, j]) for j, k in enumerate(METRIC_KEYS[:-1])}
+                y.metrics["grid_size"] = G
     return loss, out, stt
 
 
-def train_backward_bf16(model, stt, grad_scale=1.0):
+def train_backward_bf16(model, stt, grad_scale=None):
+    """walks the plan in reverse; every parameter gradient is ADDED into ``p.grad`` (created as zeros where missing)"""
     L = _lib.lib()
     st = _lib.stream_ptr()
     graph = model._graph
     B, S = stt.B, stt.S
-    dev = torch.device("cuda", torch.cuda.current_device())
+    ctx = stt.ctx
+    pool = ctx.pool
+    packed = ctx.packed
+    dev = ctx.dev
     dval = {}
+    for p in model.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    hook = getattr(model, "_grad_ready", None)
+    keep_dz = getattr(model, "_dbg_keep_dz", None)
 
     def size_of(i):
         return S >> graph[i]["log2_down"] if i >= 0 else S
 
-    def acc(j, t):
-        """accumulate the blocked-bf16 gradient t into layer j's output gradient"""
+    def acc(j, t, own):
+        """accumulate the blocked-bf16 gradient t into layer j's output gradient; `own`: t came from the pool and may be kept"""
         if j < 0:
+            if own:
+                pool.put(t)
             return
         if j not in dval:
-            dval[j] = t.clone()
+            if own:
+                dval[j] = t
+            else:
+                c = pool.get(t.shape)
+                c.copy_(t)
+                dval[j] = c
         else:
             check(L.ay_accumulate_bf16(ptr(dval[j]), ptr(t), t.numel(), st), "ay_accumulate_bf16")
+            if own:
+                pool.put(t)
 
-    grads = {}
+    if grad_scale is not None:   # d(loss)/d(loss) handed down by autograd: a device scalar, applied without a host sync
+        for dh in stt.dhead.values():
+            dh.mul_(grad_scale)
     for i in range(len(graph) - 1, -1, -1):
         e = graph[i]
         t = e["type"]
@@ -218,17 +338,18 @@ def train_backward_bf16(model, stt, grad_scale=1.0):
             h = size_of(i)
             ctot = e["channels"]
             if len(parts) == 1 and parts[0][2] == 0 and parts[0][1] == ctot:
-                acc(parts[0][0], d)
+                acc(parts[0][0], d, True)
             else:
                 c0 = 0
                 for base, cj, up in parts:
                     hs = h >> up
                     first = base not in dval
                     if first:
-                        dval[base] = torch.empty(B, cj // 16, hs, hs, 16, device=dev, dtype=torch.bfloat16)
+                        dval[base] = pool.get((B, cj // 16, hs, hs, 16))
                     check(L.ay_slice_accumulate_bf16(ptr(d), ptr(dval[base]), B, cj, ctot, c0, h, h, up, 0 if first else 1, st),
                           "ay_slice_accumulate_bf16")
                     c0 += cj
+                pool.put(d)
             continue
         if t == "upsample":
             if i in dval:
@@ -236,8 +357,9 @@ def train_backward_bf16(model, stt, grad_scale=1.0):
                 c, h = e["channels"], size_of(i)
                 first = e["src"] not in dval
                 if first:
-                    dval[e["src"]] = torch.empty(B, c // 16, h // 2, h // 2, 16, device=dev, dtype=torch.bfloat16)
+                    dval[e["src"]] = pool.get((B, c // 16, h // 2, h // 2, 16))
                 check(L.ay_slice_accumulate_bf16(ptr(d), ptr(dval[e["src"]]), B, c, c, 0, h, h, 1, 0 if first else 1, st), "ay_slice_accumulate_bf16")
+                pool.put(d)
             continue
         if t == "shortcut":
             continue  # handled with the fused convolution at i-1 (its gradient stays in dval[i])
@@ -253,69 +375,68 @@ def train_backward_bf16(model, stt, grad_scale=1.0):
             dh = stt.dhead.get(i + 1)
             if dh is None:
                 continue
-            db = torch.empty(cout, device=dev, dtype=torch.float32)
-            check(L.ay_bias_grad_f32(ptr(dh), ptr(db), B, cout, hout * hout, st), "ay_bias_grad_f32")
-            grads[conv.bias] = db
-            dz = torch.empty(B, rec["cpad"] // 16, hout, hout, 16, device=dev, dtype=torch.bfloat16)
+            check(L.ay_bias_grad_f32_acc(ptr(dh), ptr(conv.bias.grad), 1, B, cout, hout * hout, st), "ay_bias_grad_f32")
+            dz = pool.get((B, rec["cpad"] // 16, hout, hout, 16))
+            if rec["cpad"] != _pad(cout, 16):  # planes between ceil16(cout) and cpad are not written by the converter
+                dz[:, _pad(cout, 16) // 16:].zero_()
             check(L.ay_nchw_f32_to_blocked_bf16(ptr(dh), ptr(dz), B, cout, hout, hout, st), "ay_nchw_f32_to_blocked_bf16")
         else:
             if rec.get("fused"):
                 if i + 1 not in dval:
                     continue
                 dy = dval.pop(i + 1)
-                acc(graph[i + 1]["b"], dy)      # the shortcut's skip operand gets the same gradient
             else:
                 if i not in dval:
                     continue
                 dy = dval.pop(i)
             bn = m[1]
-            dz = torch.empty_like(rec["z"])
-            dg = torch.empty(cout, device=dev, dtype=torch.float32)
-            db = torch.empty(cout, device=dev, dtype=torch.float32)
-            check(L.ay_bn_train_bwd_bf16(ptr(dy), ptr(rec["z"]), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(rec["mean"]), ptr(rec["invstd"]),
-                                         int(e["leaky"]), ptr(dz), ptr(dg), ptr(db), ptr(rec["keep"][1]), B, cout, hout, hout, st), "ay_bn_train_bwd_bf16")
-            grads[bn.weight], grads[bn.bias] = dg, db
-        if getattr(model, "_dbg_keep_dz", None) is not None and i in model._dbg_keep_dz:
-            model._dbg_keep_dz[i] = dz
-        # ---- weight gradient (matrix cores, K = pixels)
+            dz = pool.get(tuple(rec["z"].shape))
+            check(L.ay_bn_train_bwd_bf16_acc(ptr(dy), ptr(rec["z"]), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(rec["mean"]), ptr(rec["invstd"]),
+                                             int(e["leaky"]), ptr(dz), ptr(bn.weight.grad), ptr(bn.bias.grad), ptr(rec["ws"]), 1, B, cout, hout, hout, st),
+                  "ay_bn_train_bwd_bf16")
+            if rec.get("fused"):
+                # the shortcut's skip operand gets the same gradient: dy itself moves on (the BN backward above only read it, and
+                # whatever accumulates into it later is issued later on the same stream) -- no copy
+                acc(graph[i + 1]["b"], dy, True)
+            else:
+                pool.put(dy)
+        if keep_dz is not None and i in keep_dz:
+            keep_dz[i] = dz.clone()
+        # ---- weight gradient (matrix cores, K = pixels), added into conv.weight.grad
         if rec.get("stem"):
             d_w = ConvDesc(B, cin, cout, hin, hin, hout, hout, k, e["stride"], 0, 0, rec["cpad"])  # cin = 3: rows ci >= 3 of the plane are skipped
         else:
             d_w = d
-        dw = torch.empty_like(rec["w"])
-        check(L.ay_conv_wgrad_bf16(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(dw), st), "ay_conv_wgrad_bf16")
-        grads[conv.weight] = dw
+        check(L.ay_conv_wgrad_bf16_acc(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, st), "ay_conv_wgrad_bf16")
+        if hook is not None:
+            hook(i)
         # ---- data gradient: the forward kernel on flipped / transposed filters
         j = rec["src"]
         if j < 0:
+            pool.put(dz)
             continue
-        cin_pad = _pad(cin, 32)
+        pk = packed[i]
+        cin_pad = pk["cin_pad"]
         kin = rec["cpad"]                       # channels of dz's planes (>= cout, multiple of 32)
-        packed = torch.empty((kin // 16) * k * k * 2 * cin_pad * 8 * 2, device=dev, dtype=torch.uint8)
-        if kin != _pad(cout, 16):               # zero rows for the planes between ceil16(cout) and kin
-            packed.zero_()
-        check(L.ay_pack_dgrad_weights_bf16(ptr(rec["w"]), ptr(packed), cout, cin, cin_pad, k, st), "ay_pack_dgrad_weights_bf16")
         src_dz = dz
         if e["stride"] == 2:
-            up = torch.empty(B, kin // 16, hin, hin, 16, device=dev, dtype=torch.bfloat16)
+            up = pool.get((B, kin // 16, hin, hin, 16))
             check(L.ay_zero_insert_bf16(ptr(dz), ptr(up), B, kin, hout, hout, hin, hin, st), "ay_zero_insert_bf16")
             src_dz = up
         ones, zeros = model._unit(cin_pad, dev)
         dd = ConvDesc(B, kin, cin, hin, hin, hin, hin, k, 1, 0, 0, cin_pad)
         first = j not in dval
         if first:
-            dval[j] = torch.empty(B, cin_pad // 16, hin, hin, 16, device=dev, dtype=torch.bfloat16)
-        check(L.ay_conv_fwd_bf16(C.byref(dd), ptr(src_dz), ptr(packed), ptr(ones), ptr(zeros), None if first else ptr(dval[j]), ptr(dval[j]), st),
+            dval[j] = pool.get((B, cin_pad // 16, hin, hin, 16))
+        check(L.ay_conv_fwd_bf16(C.byref(dd), ptr(src_dz), ptr(pk["dgrad"]), ptr(ones), ptr(zeros), None if first else ptr(dval[j]), ptr(dval[j]), st),
               "ay_conv_fwd_bf16(dgrad)")
-    out = []
-    for p in model.parameters():
-        g = grads.get(p)
-        if g is None:
-            g = torch.zeros_like(p)
-        elif grad_scale != 1.0:
-            g = g * grad_scale
-        out.append(g)
-    return out
+        pool.put(dz)
+        if src_dz is not dz:
+            pool.put(src_dz)
+    for t in dval.values():
+        pool.put(t)
+    if hook is not None:
+        hook(-1)
 
 
 class TrainStepBf16(torch.autograd.Function):
@@ -328,7 +449,7 @@ class TrainStepBf16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_out):
-        gs = float(grad_loss.item()) if grad_loss is not None else 1.0
-        grads = train_backward_bf16(ctx.model, ctx.stt, gs)
+        train_backward_bf16(ctx.model, ctx.stt, grad_loss)   # adds into every p.grad itself
+        n = len(list(ctx.model.parameters()))
         ctx.stt = None
-        return (None, None, None) + tuple(grads)
+        return (None, None, None) + (None,) * n

@@ -261,11 +261,13 @@ def bench_train(a, rank, local_rank, world, dev):
     x = torch.from_numpy(synth.synth_tiles(nu, S, start=100 + rank * nu)).to(dev)
     x = x.repeat((B + nu - 1) // nu, 1, 1, 1)[:B].contiguous()
     tg = torch.from_numpy(synth.synth_targets(B, a.classes, seed=77 + rank, grid=S // 8)).to(dev)
-    red = FlatGradReducer(model.parameters(), n_buckets=4)
+    red = FlatGradReducer(model.parameters(), n_buckets=4).attach(model)
     opt = FlatAdam(red)
     losses = []
+    model.collect_metrics = False   # the per-layer metric table (one host sync per step) is train()'s logging, not the step
 
     def step():
+        red.begin()                 # N > 1: each bucket's all-reduce is issued from inside the backward walk
         loss, _ = model.train_step_device(x, tg)
         loss.backward()
         red.all_reduce(average=False)

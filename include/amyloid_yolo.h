@@ -173,6 +173,7 @@ int ay_bn_train_bwd_f32(const float* dy, const float* y, const float* z, const f
                         const float* save_invstd, int leaky, float* dz, float* dgamma, float* dbeta, int batch,
                         int channels, int hw, ay_stream_t stream);
 int ay_bias_grad_f32(const float* dz, float* dbias, int batch, int channels, int hw, ay_stream_t stream);
+int ay_bias_grad_f32_acc(const float* dz, float* dbias, int accumulate, int batch, int channels, int hw, ay_stream_t stream);
 /* autograd of nn.Conv2d (models.py:33-40): input gradient (optionally accumulated into dx) and weight gradient */
 int ay_conv_dgrad_f32(const ay_conv_desc* d, const float* dz, const float* w_oihw, float* dx, int accumulate,
                       ay_stream_t stream);
@@ -250,6 +251,12 @@ int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const float* beta, f
 int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, int batch,
                          int channels, int h, int w, ay_stream_t stream);
+/* The `_acc` forms with accumulate != 0 ADD the parameter gradients to what dgamma / dbeta / dw / dbias hold: the parameter
+ * gradients of a step go straight into the caller's (flat) gradient buffer, also across the batches of a gradient
+ * accumulation (train.py:116-119), instead of through per-layer temporaries and autograd's accumulation pass. */
+int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
+                             int accumulate, int batch, int channels, int h, int w, ay_stream_t stream);
 int ay_accumulate_bf16(void* dst, const void* src, size_t n_elems, ay_stream_t stream);
 /* route / nearest-upsample backward on blocked tensors (channel counts multiples of 16) */
 int ay_slice_accumulate_bf16(const void* dout, void* dsrc, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
@@ -262,6 +269,8 @@ int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int 
 /* weight gradient on the MFMA path: dW (OIHW fp32, overwritten) from blocked bf16 input x and output gradient dz
  * (desc as in the forward; cout_pad = channels of dz's planes) */
 int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream);
+int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
+                           ay_stream_t stream);
 
 /* ---- inference plan: Darknet.forward (models.py:237-255) lowered to a flat op list ------------------------------
  * The host lowers the cfg graph once (which layers fuse, which routes fold into a loader) and hands the ops over; the

@@ -165,6 +165,10 @@ CONV_CASES = [
     (256, 512, 3, 1, 16, True, True, False, 2),    # exactly one tile row; 4 channel groups; 16 stages
     (128, 128, 3, 1, 20, False, True, False, 1),   # linear, batch 1
     (32, 128, 3, 1, 33, True, False, False, 2),    # a single stage pair, 33 = one pixel into the second tile column / third row
+    # 32-channel tile of the ring kernel (stem through the MFMA kernels, data gradients into 32 channels)
+    (16, 32, 3, 1, 40, True, False, False, 2),
+    (64, 32, 3, 1, 24, False, True, False, 3),     # with accumulation through the residual operand
+    (64, 32, 1, 1, 20, False, True, False, 2),
 ]
 
 
