@@ -94,47 +94,79 @@ class ImageFolder(Dataset):
         return len(self.files)
 
 
+def label_path_of(image_path):
+    """the annotation contract: .../images/x.jpg|png -> .../labels/x.txt"""
+    stem = image_path.replace("images", "labels")
+    for ext in (".png", ".jpg"):
+        stem = stem.replace(ext, ".txt")
+    return stem
+
+
+def read_sample(image_path):
+    """(uint8 HWC image, boxes [n,5] = class cx cy w h) of one tile, or None when either file cannot be read (such samples
+    are skipped by the collate step, as in the reference: ``utils/datasets.py:93-95,107-109``)"""
+    try:
+        img = np.asarray(Image.open(image_path).convert("RGB"), dtype=np.uint8)
+    except Exception as exc:
+        warnings.warn(f"skipping {image_path}: image not readable ({exc})")
+        return None
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # an empty label file is a tile without boxes
+            boxes = np.loadtxt(label_path_of(image_path)).reshape(-1, 5)
+    except Exception as exc:
+        warnings.warn(f"skipping {image_path}: labels not readable ({exc})")
+        return None
+    return img, boxes
+
+
+class SizeSchedule:
+    """multi-scale training (reference ``utils/datasets.py:78-79,131-133``): every 10th batch a new side is drawn from
+    [base - 96, base + 96] in steps of 32"""
+
+    def __init__(self, base, enabled):
+        self.size = base
+        self.enabled = enabled
+        self.choices = list(range(base - 96, base + 96 + 1, 32))
+        self.batches = 0
+
+    def next(self):
+        self.batches += 1
+        if self.enabled and self.batches % 10 == 0:
+            self.size = random.choice(self.choices)
+        return self.size
+
+
 class ListDataset(Dataset):
-    """list file of image paths; labels at images->labels, .jpg/.png->.txt (reference ``utils/datasets.py:65-143``)"""
+    """Training / evaluation set given as a text file of image paths (reference ``utils/datasets.py:65-143``); items are
+    (path, float image [3,S',S'] padded to square, targets [n,6] with column 0 left for the sample index)."""
 
     def __init__(self, list_path, img_size=416, multiscale=True):
-        with open(list_path, "r") as fh:
-            self.img_files = [l for l in fh.readlines() if l.strip()]
-        self.label_files = [p.replace("images", "labels").replace(".png", ".txt").replace(".jpg", ".txt") for p in self.img_files]
-        self.img_size = img_size
-        self.multiscale = multiscale
-        self.min_size = self.img_size - 3 * 32
-        self.max_size = self.img_size + 3 * 32
-        self.batch_count = 0
+        with open(list_path) as fh:
+            self.img_files = [line.strip() for line in fh if line.strip()]
+        self.schedule = SizeSchedule(img_size, multiscale)
 
-    def __getitem__(self, index):
-        try:
-            img_path = self.img_files[index % len(self.img_files)].rstrip()
-            img = np.array(Image.open(img_path).convert("RGB"), dtype=np.uint8)
-        except Exception:
-            print(f"Could not read image '{img_path}'.")
-            return None
-        try:
-            label_path = self.label_files[index % len(self.img_files)].rstrip()
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                boxes = np.loadtxt(label_path).reshape(-1, 5)
-        except Exception:
-            print(f"Could not read label '{label_path}'.")
-            return None
-        img, targets = default_transform(img, boxes)
-        return img_path, img, targets
-
-    def collate_fn(self, batch):
-        self.batch_count += 1
-        batch = [d for d in batch if d is not None]
-        paths, imgs, targets = list(zip(*batch))
-        if self.multiscale and self.batch_count % 10 == 0:
-            self.img_size = random.choice(range(self.min_size, self.max_size + 1, 32))
-        imgs = torch.stack([resize(img, self.img_size) for img in imgs])
-        for i, boxes in enumerate(targets):
-            boxes[:, 0] = i
-        return paths, imgs, torch.cat(targets, 0)
+    @property
+    def img_size(self):
+        return self.schedule.size
 
     def __len__(self):
         return len(self.img_files)
+
+    def __getitem__(self, index):
+        path = self.img_files[index % len(self.img_files)]
+        sample = read_sample(path)
+        if sample is None:
+            return None
+        img, targets = default_transform(*sample)
+        return path, img, targets
+
+    def collate_fn(self, batch):
+        """drop unreadable samples, bring every image to the batch's side (nearest), number the targets by sample"""
+        size = self.schedule.next()
+        kept = [item for item in batch if item is not None]
+        paths = tuple(item[0] for item in kept)
+        imgs = torch.stack([resize(item[1], size) for item in kept])
+        for k, item in enumerate(kept):
+            item[2][:, 0] = k
+        return paths, imgs, torch.cat([item[2] for item in kept], 0)

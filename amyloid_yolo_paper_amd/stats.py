@@ -43,34 +43,48 @@ def get_batch_statistics(outputs, targets, iou_threshold):
     return batch_metrics
 
 
-def compute_ap(recall, precision):
-    mrec = np.concatenate(([0.0], recall, [1.0]))
-    mpre = np.concatenate(([0.0], precision, [0.0]))
-    for i in range(mpre.size - 1, 0, -1):
-        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
-    i = np.where(mrec[1:] != mrec[:-1])[0]
-    return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+def _class_segments(keys):
+    """sorted integer keys -> (unique keys, start index of each run, one-past-the-end index of each run)"""
+    cut = np.flatnonzero(np.diff(keys)) + 1
+    starts = np.concatenate(([0], cut))
+    return keys[starts], starts, np.concatenate((cut, [keys.size]))
+
+
+def average_precision(true_pos, n_truth):
+    """Area under the monotone precision envelope of ONE class (the reference's VOC-style ``compute_ap``,
+    ``utils/utils.py:126-150``), from the true-positive flags of its detections in descending-confidence order.
+    Returns (ap, final precision, final recall).  The curve is walked once from the right: the envelope value at a
+    detection is the best precision at or after it, and the area grows by (recall step) x (envelope) wherever the recall
+    moves -- i.e. at the true positives -- plus the closing step to recall 1 at precision 0, which adds nothing."""
+    hits = np.cumsum(true_pos)
+    false_alarms = np.cumsum(1.0 - true_pos)
+    precision = hits / (hits + false_alarms)
+    recall = hits / (n_truth + 1e-16)
+    envelope = np.maximum.accumulate(precision[::-1])[::-1]
+    step = np.diff(np.concatenate(([0.0], recall)))
+    moved = step != 0
+    return float(np.sum(step[moved] * envelope[moved])), float(precision[-1]), float(recall[-1])
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls):
-    tp, conf, pred_cls, target_cls = (np.asarray(v) for v in (tp, conf, pred_cls, target_cls))
-    order = np.argsort(-conf)
-    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
-    unique_classes = np.unique(target_cls)
-    ap, p, r = [], [], []
-    for c in unique_classes:
-        sel = pred_cls == c
-        n_gt, n_p = (target_cls == c).sum(), sel.sum()
-        if n_p == 0 and n_gt == 0:
-            continue
-        if n_p == 0 or n_gt == 0:
-            ap.append(0); r.append(0); p.append(0)
-            continue
-        fpc, tpc = (1 - tp[sel]).cumsum(), tp[sel].cumsum()
-        recall_curve = tpc / (n_gt + 1e-16)
-        precision_curve = tpc / (tpc + fpc)
-        r.append(recall_curve[-1]); p.append(precision_curve[-1])
-        ap.append(compute_ap(recall_curve, precision_curve))
-    p, r, ap = np.array(p), np.array(r), np.array(ap)
-    f1 = 2 * p * r / (p + r + 1e-16)
-    return p, r, ap, f1, unique_classes.astype("int32")
+    """Reference ``utils/utils.py:71-123``: precision, recall, AP, F1 per ground-truth class (and the class ids, int32), from
+    the flat per-detection arrays of a whole evaluation.  One stable sort by (class, descending confidence) lays every
+    class's detections out as a contiguous run; classes that occur only among the detections are ignored, a
+    ground-truth class without detections scores zero."""
+    tp = np.asarray(tp, np.float64)
+    conf = np.asarray(conf)
+    pred_cls = np.asarray(pred_cls)
+    truth_ids, truth_counts = np.unique(np.asarray(target_cls), return_counts=True)
+    order = np.lexsort((-conf, pred_cls))           # primary key: class, secondary: confidence descending (stable)
+    tp, pred_sorted = tp[order], pred_cls[order]
+    runs = {}
+    if pred_sorted.size:
+        ids, lo, hi = _class_segments(pred_sorted)
+        runs = {c: (a, b) for c, a, b in zip(ids.tolist(), lo.tolist(), hi.tolist())}
+    prec, rec, ap = (np.zeros(truth_ids.size) for _ in range(3))
+    for k, (c, n_truth) in enumerate(zip(truth_ids.tolist(), truth_counts.tolist())):
+        if c in runs:
+            a, b = runs[c]
+            ap[k], prec[k], rec[k] = average_precision(tp[a:b], n_truth)
+    f1 = 2 * prec * rec / (prec + rec + 1e-16)
+    return prec, rec, ap, f1, truth_ids.astype("int32")

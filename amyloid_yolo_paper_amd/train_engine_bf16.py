@@ -30,6 +30,29 @@ def _pad(v, m):
     return (v + m - 1) // m * m
 
 
+def _family(e):
+    """the 3x3 stride-1 layers with a multiple of 128 filters: 76 % of the model's FLOPs"""
+    return e["k"] == 3 and e["stride"] == 1 and e["cout"] % 128 == 0 and e["cin"] % 32 == 0
+
+
+class _Timed:
+    """bench.py --mode train: HIP event pairs (on the stream the kernels are issued to) around one kind of launch;
+    model._train_prof = {"wgrad": [], "conv": []} turns it on"""
+
+    def __init__(self, prof, kind, on):
+        self.lst = prof[kind] if (prof is not None and on) else None
+
+    def __enter__(self):
+        if self.lst is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.lst is not None:
+            self.e1.record()
+            self.lst.append((self.e0, self.e1))
+
+
 class _State:
     """what one forward leaves for its backward (tests read .conv[i]["z"], .val[i])"""
 
@@ -172,6 +195,7 @@ def train_forward_bf16(model, x, targets):
 
     row = 0
     sums_all = []
+    prof = getattr(model, "_train_prof", None)
     for i, e in enumerate(graph):
         t = e["type"]
         if t == "convolutional":
@@ -206,7 +230,8 @@ def train_forward_bf16(model, x, targets):
             bn = m[1]
             assert cout % 32 == 0, f"layer {i}: the bf16 training path needs BN layers with a multiple of 32 filters (got {cout})"
             z = blocked(("z", i), cout, hout, pad=32)
-            check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
+            with _Timed(prof, "conv", _family(e)):
+                check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
             fuse = e["fuse_into_shortcut"]
             skip = resolve(graph[i + 1]["b"]) if fuse else None
             y = blocked(("y", i), cout, hout, pad=32)
@@ -300,6 +325,7 @@ def train_backward_bf16(model, stt, grad_scale=None):
             p.grad = torch.zeros_like(p)
     hook = getattr(model, "_grad_ready", None)
     keep_dz = getattr(model, "_dbg_keep_dz", None)
+    prof = getattr(model, "_train_prof", None)
 
     def size_of(i):
         return S >> graph[i]["log2_down"] if i >= 0 else S
@@ -407,7 +433,8 @@ def train_backward_bf16(model, stt, grad_scale=None):
             d_w = ConvDesc(B, cin, cout, hin, hin, hout, hout, k, e["stride"], 0, 0, rec["cpad"])  # cin = 3: rows ci >= 3 of the plane are skipped
         else:
             d_w = d
-        check(L.ay_conv_wgrad_bf16_acc(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, st), "ay_conv_wgrad_bf16")
+        with _Timed(prof, "wgrad", _family(e)):
+            check(L.ay_conv_wgrad_bf16_acc(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, st), "ay_conv_wgrad_bf16")
         if hook is not None:
             hook(i)
         # ---- data gradient: the forward kernel on flipped / transposed filters
@@ -428,8 +455,10 @@ def train_backward_bf16(model, stt, grad_scale=None):
         first = j not in dval
         if first:
             dval[j] = pool.get((B, cin_pad // 16, hin, hin, 16))
-        check(L.ay_conv_fwd_bf16(C.byref(dd), ptr(src_dz), ptr(pk["dgrad"]), ptr(ones), ptr(zeros), None if first else ptr(dval[j]), ptr(dval[j]), st),
-              "ay_conv_fwd_bf16(dgrad)")
+        # (timed with the family where the data gradient is itself a 3x3 s1 convolution onto a multiple of 128 channels)
+        with _Timed(prof, "conv", _family(e) and e["stride"] == 1 and cin % 128 == 0):
+            check(L.ay_conv_fwd_bf16(C.byref(dd), ptr(src_dz), ptr(pk["dgrad"]), ptr(ones), ptr(zeros), None if first else ptr(dval[j]), ptr(dval[j]), st),
+                  "ay_conv_fwd_bf16(dgrad)")
         pool.put(dz)
         if src_dz is not dz:
             pool.put(src_dz)

@@ -146,17 +146,25 @@ def nms_workspace(B, N, dev, slot=0):
     return ws
 
 
+_nms_out_cache = {}
+
+
 def nms_device(pred_dev, conf_thres, nms_thres, max_det, slot=0):
     """Raw fused device call (no host sync) on the current stream: pred_dev [B,N,5+C] float32 CUDA tensor, corners IN PLACE.
     Returns (rows [B,max_det,7], keep [B,max_det] i32, count [B] i32, cand_count [B] i32) device tensors;
-    ``count[b] > max_det`` means image b had more cluster heads than the buffers hold."""
+    ``count[b] > max_det`` means image b had more cluster heads than the buffers hold.
+    The four result tensors are persistent per (device, slot, batch, max_det) -- valid until the next call with the same slot --
+    so a steady-state step allocates nothing (and a HIP graph captured around it replays into the same addresses)."""
     L = _lib.lib()
     B, N, K = pred_dev.shape
     dev = pred_dev.device
-    rows = torch.empty(B, max_det, 7, device=dev, dtype=torch.float32)
-    keep = torch.empty(B, max_det, device=dev, dtype=torch.int32)
-    count = torch.empty(B, device=dev, dtype=torch.int32)
-    cand = torch.empty(B, device=dev, dtype=torch.int32)
+    key = (str(dev), slot, B, max_det)
+    bufs = _nms_out_cache.get(key)
+    if bufs is None:
+        bufs = (torch.empty(B, max_det, 7, device=dev, dtype=torch.float32), torch.empty(B, max_det, device=dev, dtype=torch.int32),
+                torch.empty(B, device=dev, dtype=torch.int32), torch.empty(B, device=dev, dtype=torch.int32))
+        _nms_out_cache[key] = bufs
+    rows, keep, count, cand = bufs
     ws = nms_workspace(B, N, dev, slot)
     check(L.ay_nms_merge(ptr(pred_dev), B, N, K - 5, C.c_float(conf_thres), C.c_float(nms_thres), max_det, ptr(rows), ptr(keep),
                          ptr(count), ptr(cand), ptr(ws), ws.numel(), _lib.stream_ptr()), "ay_nms_merge")

@@ -281,6 +281,9 @@ def bench_train(a, rank, local_rank, world, dev):
     if USE_DIST:
         dist.barrier()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    if not a.no_layer_events:
+        model._train_prof = {"wgrad": [], "conv": []}   # HIP event pairs around the 3x3 family's launches (issue stream)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses.append(step())
@@ -295,20 +298,75 @@ def bench_train(a, rank, local_rank, world, dev):
     lv = [float(l.item()) for l in losses]
     assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite training loss"
     flops_per_img = 3.0 * sum(conv_flops(e, 1, 1024) for e in model._graph if e["type"] == "convolutional") * (S / 1024.0) ** 2
+    ctx_bytes = sum(c.bytes() for c in getattr(model, "_train_ctx", {}).values())
     result = {
         "metric": "train imgs/sec", "value": round(world * B * a.steps / elapsed, 2), "unit": "imgs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"configs[2]: random-init YOLOv3 C={a.classes}, batch={B}/GPU, {S}x{S} synthetic tiles + boxes, train-mode BN, "
-                               f"loss + backward + {'RCCL all-reduce (246 MB fp32, 4 buckets) + ' if world > 1 else ''}Adam",
+                               f"loss + backward + {'RCCL all-reduce (246 MB fp32, 4 buckets, issued from inside the backward) + ' if world > 1 else ''}Adam",
                    "global_batch": world * B, "tile": S, "parallelism": f"dp{world}", "first_loss": round(lv[0], 3), "last_loss": round(lv[-1], 3),
-                   "model_tflops": round(world * B * a.steps * flops_per_img / elapsed / 1e12, 1)},
+                   "model_tflops": round(world * B * a.steps * flops_per_img / elapsed / 1e12, 1),
+                   "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "saved_activations_gb": round(ctx_bytes / 1e9, 1)},
     }
+    prof = getattr(model, "_train_prof", None)
+    if prof and prof["wgrad"]:
+        fam = [e for e in model._graph if e["type"] == "convolutional" and e["k"] == 3 and e["stride"] == 1 and e["cout"] % 128 == 0 and e["cin"] % 32 == 0]
+        fl_w = sum(conv_flops(e, B, S) for e in fam)                                        # weight gradients of the family, per step
+        fl_c = fl_w + sum(conv_flops(e, B, S) for e in fam if e["cin"] % 128 == 0)           # forward + the timed data gradients
+        ms_w = sum(e0.elapsed_time(e1) for e0, e1 in prof["wgrad"])
+        ms_c = sum(e0.elapsed_time(e1) for e0, e1 in prof["conv"])
+        ach_w = fl_w * a.steps / (ms_w * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(ach_w, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_w / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "kernel": "ay::wgrad_bf16_kernel<3,1> (weight gradient of the 3x3 s1 family: the largest share of the step)",
+            "launches_per_step": len(prof["wgrad"]) // a.steps, "avg_launch_ms": round(ms_w / len(prof["wgrad"]), 4),
+            "share_of_step": round(ms_w / a.steps / (1e3 * elapsed / a.steps), 3),
+            "conv_family": {"kernel": "ay::conv3x3_m16_ring_kernel (forward + data gradient of the same layers)",
+                            "achieved": round(fl_c * a.steps / (ms_c * 1e-3) / 1e12, 1), "frac": round(fl_c * a.steps / (ms_c * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                            "launches_per_step": len(prof["conv"]) // a.steps, "share_of_step": round(ms_c / a.steps / (1e3 * elapsed / a.steps), 3)},
+        }
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_train_baseline(a)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if USE_DIST:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_train_baseline(a):
+    """BASELINE.md section 3, training leg: the CPU oracle (fp32 torch-CPU autograd through the restated graph and loss, pinned to
+    the reference's training step by tests/golden/train_*.npz), B=2 at 416^2, 1 warm-up + 4 timed steps with torch.optim.Adam."""
+    import torch
+    from amyloid_yolo_paper_amd import cfg_gen, synth
+    from oracle.darknet_oracle import OracleDarknet
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    B, S = 2, 416
+    m = OracleDarknet(cfg_gen.write_cfg(a.classes))
+    g = torch.Generator().manual_seed(1234)
+    for p in m.params.values():
+        p["weight"] = torch.randn(p["weight"].shape, generator=g) * 0.02
+        if "gamma" in p:
+            p["gamma"] = 1.0 + 0.02 * torch.randn(p["gamma"].shape, generator=g)
+    m.require_grad()
+    params = [t for p in m.params.values() for k, t in p.items() if k in ("weight", "gamma", "beta", "bias")]
+    opt = torch.optim.Adam(params)
+    x = torch.from_numpy(synth.synth_tiles(B, S, start=100))
+    tg = torch.from_numpy(synth.synth_targets(B, a.classes, seed=77, grid=S // 8))
+    times = []
+    for it in range(5):
+        t0 = time.perf_counter()
+        loss, _ = m.forward(x, tg, train_bn=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:])
+    return {"value": round(B * 4 / dt, 3), "unit": "imgs/s", "cores": cores, "kind": "port",
+            "sample": f"4 timed steps (after 1 warm-up) of batch {B} at {S}x{S}: forward (train-mode BN) + loss + backward + Adam, fp32 torch-CPU "
+                      f"autograd through the restated graph on {cores} threads ({dt:.1f} s); the GPU line is batch {a.train_batch} at {a.train_size}^2"}
 
 
 def host_cores():

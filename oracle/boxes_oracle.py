@@ -59,7 +59,8 @@ def bbox_iou(box1, box2, x1y1x2y2=True):
 
 
 def bbox_giou(box1, box2):
-    """GIoU, corner boxes, no +1 rule.  PARITY UNPINNED: the reference has no GIoU."""
+    """GIoU, corner boxes, no +1 rule.  The reference has no GIoU: this function is pinned by the closed-form vectors
+    of the published definition instead (tests/golden/giou_kat.json, oracle/gen_golden_giou.py; tests/test_oracle_golden.py)."""
     box1 = np.asarray(box1, F32).reshape(-1, 4)
     box2 = np.asarray(box2, F32).reshape(-1, 4)
     iw = np.maximum(np.minimum(box1[:, 2], box2[:, 2]) - np.maximum(box1[:, 0], box2[:, 0]), F32(0))

@@ -176,3 +176,20 @@ def test_eval_statistics_oracle_vs_reference(golden_dir, thr):
     for got, name in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1")):
         np.testing.assert_allclose(got, z[f"{tag}_{name}"], rtol=1e-12, atol=0)
     np.testing.assert_array_equal(cls, z[f"{tag}_cls"])
+
+
+def test_giou_closed_form_vectors(golden_dir):
+    """oracle GIoU (corner form and the differentiable cxcywh form the loss uses) against exact rationals of the published
+    definition on integer boxes (tests/golden/giou_kat.json): the reference has no GIoU, these vectors are the pin."""
+    import json
+    from oracle.darknet_oracle import giou_cxcywh
+    doc = json.load(open(os.path.join(golden_dir, "giou_kat.json")))
+    b1 = np.array([c["box1"] for c in doc["cases"]], np.float32)
+    b2 = np.array([c["box2"] for c in doc["cases"]], np.float32)
+    want = np.array([c["giou"][0] / c["giou"][1] for c in doc["cases"]])
+    np.testing.assert_allclose(bo.bbox_giou(b1, b2), want, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(bo.bbox_giou(b2, b1), want, rtol=0, atol=2e-7)          # symmetric
+
+    def cxcywh(b):
+        return torch.tensor(np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1))
+    np.testing.assert_allclose(giou_cxcywh(cxcywh(b1), cxcywh(b2)).numpy(), want, rtol=0, atol=2e-7)
