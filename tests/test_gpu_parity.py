@@ -440,8 +440,11 @@ def test_detect_end_to_end(tmp_cfg_dir, tmp_path, dev):
 
 @pytest.mark.parametrize("case", [(64, 40, 2), (128, 32, 2), (128, 13, 1), (64, 72, 1)], ids=str)
 def test_resblock_fused_kernel(dev, case):
-    """ay_resblock_fwd_bf16 (1x1 -> 3x3 -> +x in one kernel) is BIT-identical to the two ay_conv_fwd_bf16 calls it
-    replaces (same K order, same rounding points), and within 1 bf16 ulp (+1e-3) of the torch-CPU composition."""
+    """ay_resblock_fwd_bf16 (1x1 -> 3x3 -> +x in one kernel) against the two ay_conv_fwd_bf16 calls it replaces (same rounding
+    points): BIT-identical where the 3x3 of the two-call path is the 32x32x16 kernel too (same K order: C = 64); for C = 128 the
+    two-call 3x3 runs on the 16x16x32 kernel, whose fp32 sums are taken in another order, so single elements may land on the
+    other side of a bf16 rounding boundary (at most one ulp, at most 1e-3 of the elements).  Both within 1 bf16 ulp (+1e-3)
+    of the torch-CPU composition."""
     Cc, H, B = case
     CM = Cc // 2
     L = _lib.lib()
@@ -476,7 +479,13 @@ def test_resblock_fused_kernel(dev, case):
           "resblock")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(of.float()).all())
-    assert torch.equal(of.view(torch.int16), o2.view(torch.int16)), int((of.view(torch.int16) != o2.view(torch.int16)).sum())
+    if Cc == 64:
+        assert torch.equal(of.view(torch.int16), o2.view(torch.int16)), int((of.view(torch.int16) != o2.view(torch.int16)).sum())
+    else:
+        a_, b_ = of.float(), o2.float()
+        diff = (a_ - b_).abs()
+        assert bool((diff <= b_.abs() * 2.0 ** -7 + 1e-6).all()) and float((diff > 0).float().mean()) <= 1e-3, \
+            (float(diff.max()), float((diff > 0).float().mean()))
     got = torch.empty(B, Cc, H, H, device=dev)
     check(L.ay_blocked_bf16_to_nchw_f32(ptr(of), ptr(got), B, Cc, H, H, st))
     err = (got.cpu() - ref).abs()
