@@ -209,6 +209,48 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // ---- epilogue state of this item (defined here: part of the residual is requested from inside the last stage pair)
+        typedef __attribute__((address_space(3))) const f32x4 lds_f4;
+        lds_f4* sl4 = (lds_f4*)(__attribute__((address_space(3))) const float*)(lds + SS_BASE + par * 2048);
+        const float slope = a.leaky ? 0.1f : 1.0f;
+        const size_t out_plane_px = (size_t)a.hout * a.wout;
+        const unsigned plane_bytes = (unsigned)out_plane_px * 32u;
+        const unsigned img_bytes = plane_bytes * (unsigned)(CP / 16);
+        const int b0 = __builtin_amdgcn_readfirstlane(b);
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b0 * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(HAS_RES ? a.residual : a.out) + (size_t)b0 * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const int cbase = cg * BN + wm * 64;  // first channel of this wave
+        const int col = (g & 1) * 16 + r;     // pixel column inside the tile row, byte half (g >> 1) * 16 of the 32-byte pixel
+        constexpr int NU = MT * (NT / 2);     // 16 store units
+#ifndef AY_M16_RD
+#define AY_M16_RD 8
+#endif
+#ifndef AY_M16_EARLY
+#define AY_M16_EARLY 0
+#endif
+        // residual units requested inside the last stage pair: measured SLOWER (4 units: 9 VGPRs spilled in the stage loop, 0.479 ->
+        // 0.485 ms per launch; 8 units: 28 spilled, 0.516 ms) -- the loop sits at ~246 of 256 registers -- so 0; look-ahead inside the
+        // epilogue 4 / 8 / 16 units: 0.468 / 0.468 / 0.472 ms (same-box A/B): the residual epilogue is not a latency chain, it is the
+        // HBM burst of all CUs reading residual and writing output at the same time
+        constexpr int EARLY = HAS_RES ? AY_M16_EARLY : 0;
+        constexpr int RD = AY_M16_RD;         // residual look-ahead in units inside the epilogue
+        u32x4 rres[HAS_RES ? NU : 1];
+        u32x4 outv[HAS_RES ? NU : 1];
+        auto unit_off = [&](int np, bool clamp, bool& ok) __attribute__((always_inline)) -> unsigned {
+            int oy = y0 + wn * 4 + np, ox = x0 + col;
+            ok = oy < a.hout && ox < a.wout;
+            if (clamp) oy = min(oy, a.hout - 1), ox = min(ox, a.wout - 1);
+            return ((unsigned)oy * a.wout + ox) * 32u + (unsigned)(g >> 1) * 16u;
+        };
+        auto load_res = [&](int t) __attribute__((always_inline)) {
+            const int np = t / MT, m = t % MT;
+            bool ok;
+            const unsigned vo = unit_off(np, true, ok);  // clamped: always a valid address, loads stay unconditional
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 16) >> 4) * plane_bytes);
+            rres[t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo, so, 0);
+        };
+
         bf16x8 fa[2][MT], fb[4];
         // kind 0..3: pair j of the slot `sl`; kind 4: the straddle step (both slots)
         auto ld_a = [&](int kind, int sl, int m) __attribute__((always_inline)) -> bf16x8 {
@@ -297,6 +339,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
             AY_CLK(if (clk) tk_str += wall_clock64() - tkw;)
             // ---- odd stage (slot 1); the rest of stage s+2 of this item, or of stage 0 of the next, streams into slot 0
             step(I0{}, I1{}, I1{}, I1{}, I1{}, T{}, I4{}, issued, 0);
+            if constexpr (HAS_RES && EARLY > 0) {
+                // the first EARLY residual units are requested three steps (~1.4 us) before the epilogue: their round trip -- ~2 us
+                // when every CU reaches its epilogue together -- otherwise opens the epilogue with nothing to do
+                if (last_pair) {
+#pragma unroll
+                    for (int t = 0; t < EARLY; ++t) load_res(t);
+                }
+            }
             step(I1{}, I1{}, I2{}, I1{}, I0{}, T{}, I0{}, false, 0);
             step(I2{}, I1{}, I3{}, I1{}, I1{}, T{}, I0{}, false, 0);
             step(I3{}, I1{}, I0{}, I0{}, I0{}, F{}, I0{}, false, 0);
@@ -322,38 +372,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
         // pixel (q&1)*16 + r: a 16-byte store, 1 KiB contiguous per wave instruction.  The residual is loaded in that store
         // layout and brought to the accumulator layout by the same swaps (their own inverse).
         {
-            typedef __attribute__((address_space(3))) const f32x4 lds_f4;
-            lds_f4* sl4 = (lds_f4*)(__attribute__((address_space(3))) const float*)(lds + SS_BASE + par * 2048);
-            const float slope = a.leaky ? 0.1f : 1.0f;
-            const size_t out_plane_px = (size_t)a.hout * a.wout;
-            const unsigned plane_bytes = (unsigned)out_plane_px * 32u;
-            const unsigned img_bytes = plane_bytes * (unsigned)(CP / 16);
-            const int b0 = __builtin_amdgcn_readfirstlane(b);
-            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b0 * img_bytes, 0, (int)img_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint8_t*>(HAS_RES ? a.residual : a.out) + (size_t)b0 * img_bytes, 0, (int)img_bytes, 0x00020000);
-            const int cbase = cg * BN + wm * 64;  // first channel of this wave
-            const int col = (g & 1) * 16 + r;     // pixel column inside the tile row, byte half (g >> 1) * 16 of the 32-byte pixel
-            constexpr int NU = MT * (NT / 2);     // 16 store units
-            constexpr int RD = 4;                 // residual look-ahead in units
-            u32x4 rres[HAS_RES ? NU : 1];
-            u32x4 outv[HAS_RES ? NU : 1];
-            auto unit_off = [&](int np, bool clamp, bool& ok) __attribute__((always_inline)) -> unsigned {
-                int oy = y0 + wn * 4 + np, ox = x0 + col;
-                ok = oy < a.hout && ox < a.wout;
-                if (clamp) oy = min(oy, a.hout - 1), ox = min(ox, a.wout - 1);
-                return ((unsigned)oy * a.wout + ox) * 32u + (unsigned)(g >> 1) * 16u;
-            };
-            auto load_res = [&](int t) __attribute__((always_inline)) {
-                const int np = t / MT, m = t % MT;
-                bool ok;
-                const unsigned vo = unit_off(np, true, ok);  // clamped: always a valid address, loads stay unconditional
-                const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 16) >> 4) * plane_bytes);
-                rres[t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo, so, 0);
-            };
             if constexpr (HAS_RES) {
 #pragma unroll
-                for (int t = 0; t < RD; ++t) load_res(t);
+                for (int t = EARLY; t < RD; ++t) load_res(t);
             }
 #pragma unroll
             for (int np = 0; np < NT / 2; ++np) {
@@ -385,9 +406,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
                         outv[t] = v;
                         if (RD + t < NU) load_res(RD + t);
                     } else {
-                        if (ok)
-                            *reinterpret_cast<uint4*>(a.out + (size_t)b0 * img_bytes + (size_t)((cbase + m * 16) >> 4) * plane_bytes + vo) =
-                                make_uint4(v[0], v[1], v[2], v[3]);
+                        // unconditional buffer store, out-of-image lanes carry an offset past num_records (no branch per store, no
+                        // 64-bit address per lane)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (ok ? vo : 0x80000000u) + (unsigned)((cbase + m * 16) >> 4) * plane_bytes, 0, 0);
                     }
                 }
             }

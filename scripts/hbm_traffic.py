@@ -27,7 +27,7 @@ fam_bytes, fam_n = 0.0, 0
 print("layer                          fetch MB (x2)  write MB | algorithmic: in MB  out MB  residual MB | fetch/(in+res)")
 for (n, fv), (n2, wv) in zip(fs, ws):
     assert n == n2
-    if "conv_bf16" in n or "stem" in n or "resblock" in n:
+    if "conv_bf16" in n or "conv3x3_m16" in n or "stem" in n or "resblock" in n:
         i, e = convs[ci]; ci += 1
         if "resblock" in n:  # 1x1 + 3x3 + shortcut in one kernel: x in, out out, the 1x1's output never leaves the CU
             i, e1 = convs[ci]; ci += 1

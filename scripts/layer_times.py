@@ -17,7 +17,7 @@ ci, tot, groups = 0, 0.0, {}
 for r in seq:
     n = r["Kernel_Name"]
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if "conv_bf16" in n or "stem" in n or "resblock" in n:
+    if "conv_bf16" in n or "conv3x3_m16" in n or "stem" in n or "resblock" in n:
         i, e = convs[ci]; ci += 1
         S = 1024 >> e["log2_down"]
         fl = 2 * 64 * S * S * e["cout"] * e["cin"] * e["k"] ** 2
