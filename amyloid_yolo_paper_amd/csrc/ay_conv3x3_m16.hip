@@ -33,6 +33,9 @@
 
 namespace ay {
 
+#ifndef AY_M16_PRIO
+#define AY_M16_PRIO 1
+#endif
 #ifdef AY_PHASE_CLOCK
 // instrumented build only (AY_PHASE_CLOCK=1 python build.py, AY_DBG=8 at run time): 100 MHz ticks of wave 0, summed over
 // workgroups: [0] stage loops, [1] epilogues, [2] items, [3] workgroups, [4] whole kernel per workgroup, [5] waits for landed
@@ -276,10 +279,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
             constexpr int plist = decltype(PLIST)::value;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+#if AY_M16_PRIO
                 __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][m], fb[n & 3], acc[m][n], 0, 0, 0);
+#if AY_M16_PRIO
                 __builtin_amdgcn_s_setprio(2);
+#endif
                 if (n < 4) {
                     fb[n & 3] = ld_b(kind, sl, n + 4);
                     // the next step's first MFMA group needs all four filter fragments: they are requested in the first half of

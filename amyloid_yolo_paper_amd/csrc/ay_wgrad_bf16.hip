@@ -27,8 +27,6 @@ struct WgradArgs {
     int nseg_x, total_segs;
 };
 
-__device__ __attribute__((aligned(64))) uint32_t g_wgrad_zero_page[16];
-
 __device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2); }
 
 template <int KS, int STRIDE>
@@ -58,7 +56,6 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     const int cw = wave / CI_PL, iw = wave % CI_PL;
     const int cob = blockIdx.x, cib = blockIdx.y;
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_wgrad_zero_page);
     const unsigned lds_base = lds_addr_of(lds);
 
     // segments of this workgroup: blockIdx.z, + gridDim.z, ...
@@ -66,41 +63,67 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     const int nstep = (a.total_segs - seg + (int)gridDim.z - 1) / (int)gridDim.z;
     if (nstep <= 0) return;
 
-    auto issue = [&](int sg, int buf) {
+    // ---- loader.  Which unit of a tile a lane carries in piece i (plane, row / tap row, pixel slot, channel half) does not depend
+    // on the segment: the per-lane part of every address is computed ONCE, a K step adds scalars.  Pieces go through buffer
+    // descriptors (dma16_buf): descriptor base = the segment's origin in image b (the top-left corner of its halo: 64-bit scalar
+    // arithmetic, may lie before the tensor for the first row -- those lanes are masked), vector offset = the lane's constant
+    // (never negative), or 0x80000000 (out of range: reads as zero) for lanes outside the image / beyond the planes.
+    // Before, every K step redid the unit decomposition (divisions by the tile width, 64-bit addresses, a branch) per lane and
+    // piece: 61 us of a 243-us launch (128->256 3x3 at 128^2, B=16).
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned lane_off[PW];         // byte offset of the lane's unit from the segment's origin
+    int lane_dy[PW], lane_dx[PW];  // x pieces: input row / column of the unit relative to the segment's output origin (may be negative)
+    const unsigned x_plane = (unsigned)a.hin * a.win * 32u, dz_plane = (unsigned)a.ho * a.wo * 32u;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int qn = i * 8 + wave;
+        lane_off[i] = OOB;
+        lane_dy[i] = lane_dx[i] = 0;
+        if (qn < DZ_PIECES) {
+            const int u = qn * 64 + lane;
+            const int half = u & 1, slot = (u >> 1) & 31, pl = u >> 6;
+            const int cpl = cob * CO_PL + pl;
+            lane_dx[i] = swz(slot);
+            if (cpl < a.COP) lane_off[i] = (unsigned)cpl * dz_plane + (unsigned)swz(slot) * 32u + half * 16u;
+        } else if (qn < NPIECE) {
+            const int u = (qn - DZ_PIECES) * 64 + lane;
+            if (u < X_UNITS) {
+                const int half = u & 1;
+                const int t = u >> 1;
+                const int slot = t % XW, sgi = t / XW;  // sgi = ipl * KS + kh
+                const int kh = sgi % KS, ipl = sgi / KS;
+                const int cpl = cib * CI_PL + ipl;
+                lane_dy[i] = kh - PAD;
+                lane_dx[i] = swz(slot) - PAD;
+                if (cpl < a.CIP) lane_off[i] = (unsigned)cpl * x_plane + (unsigned)((kh * a.win + swz(slot)) * 32) + half * 16u;
+            }
+        }
+    }
+    auto issue = [&](int sg, int buf) __attribute__((always_inline)) {
         const int xs = sg % a.nseg_x;
         const int oy = (sg / a.nseg_x) % a.ho;
         const int b = sg / (a.nseg_x * a.ho);
         const int ox0 = xs * 32;
+        const long long org_dz = ((long long)oy * a.wo + ox0) * 32;
+        const long long org_x = ((long long)(oy * STRIDE - PAD) * a.win + (ox0 * STRIDE - PAD)) * 32;   // negative in the first row
+        const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dz) + (long long)b * a.COP * dz_plane + org_dz, 0,
+                                                                          0x7ffffffc, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.x) + (long long)b * a.CIP * x_plane + org_x, 0,
+                                                                         0x7ffffffc, 0x00020000);
+        const unsigned so_dz = 0u, so_x = 0u;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int qn = i * 8 + wave;  // wave-uniform piece id
-            const uint8_t* src = zero_page + (lane & 3) * 16;
-            int dst = DUMMY;
             if (qn < DZ_PIECES) {
-                const int u = qn * 64 + lane;
-                const int half = u & 1, slot = (u >> 1) & 31, pl = u >> 6;
-                const int ox = ox0 + swz(slot);
-                const int cpl = cob * CO_PL + pl;
-                if (cpl < a.COP && ox < a.wo) src = a.dz + ((((size_t)b * a.COP + cpl) * a.ho + oy) * a.wo + ox) * 32 + half * 16;
-                dst = buf * BUF_BYTES + qn * 1024;
+                const unsigned vo = (ox0 + lane_dx[i] < a.wo) ? lane_off[i] : OOB;
+                dma16_buf(rdz, vo, so_dz, lds_base + buf * BUF_BYTES + qn * 1024);
             } else if (qn < NPIECE) {
-                const int u = (qn - DZ_PIECES) * 64 + lane;
-                if (u < X_UNITS) {
-                    const int half = u & 1;
-                    const int t = u >> 1;
-                    const int slot = t % XW, sgi = t / XW;  // sgi = ipl * KS + kh
-                    const int kh = sgi % KS, ipl = sgi / KS;
-                    const int iy = oy * STRIDE - PAD + kh;
-                    const int ix = ox0 * STRIDE - PAD + swz(slot);
-                    const int cpl = cib * CI_PL + ipl;
-                    if (cpl < a.CIP && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-                        src = a.x + ((((size_t)b * a.CIP + cpl) * a.hin + iy) * a.win + ix) * 32 + half * 16;
-                }
-                dst = buf * BUF_BYTES + qn * 1024;
+                const int iy = oy * STRIDE + lane_dy[i], ix = ox0 * STRIDE + lane_dx[i];
+                const unsigned vo = (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) ? lane_off[i] : OOB;
+                dma16_buf(rx, vo, so_x, lds_base + buf * BUF_BYTES + qn * 1024);
+            } else {
+                dma16_buf(rx, OOB, 0u, lds_base + DUMMY);   // keeps the per-wave piece count constant (counted vmcnt waits)
             }
-            // inline-asm DMA: with the builtin hipcc placed `s_waitcnt vmcnt(0)` between the issue of stage k+3 and the first LDS
-            // read of stage k (it cannot prove the ring slots distinct), draining the whole ring every K step
-            dma16(src, lds_base + __builtin_amdgcn_readfirstlane(dst));
         }
     };
 

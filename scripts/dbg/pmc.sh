@@ -8,5 +8,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ
   i=$((i+1)); rm -rf gpurun_out/pmc_$i
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_layer_events > gpurun_out/pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -3 gpurun_out/pmc_$i.log; }
 done
-python scripts/pmc_summary.py gpurun_out/pmc_1 gpurun_out/pmc_2 gpurun_out/pmc_3 gpurun_out/pmc_4 > gpurun_out/r01_pmc_sq_v9.txt 2>&1
-head -60 gpurun_out/r01_pmc_sq_v9.txt
+python scripts/pmc_summary.py gpurun_out/pmc_1 gpurun_out/pmc_2 gpurun_out/pmc_3 gpurun_out/pmc_4 > gpurun_out/r02_pmc_sq.txt 2>&1
+head -60 gpurun_out/r02_pmc_sq.txt
