@@ -299,6 +299,9 @@ class Darknet(nn.Module):
                 entry["w0_bf16"] = w0.to(torch.bfloat16).contiguous()
             if self.precision == "bf16" and not entry["stem"]:
                 assert e["cin"] % 16 == 0, f"layer {i}: cin {e['cin']} is not a multiple of 16"
+                # blocked bf16 values are sized and strided in 16-channel planes of ceil16(channels); the kernels write
+                # cout_pad = ceil32(cout) channels: a BN layer with filters % 32 == 16 would write one plane per image too many
+                assert not e["bn"] or cout % 32 == 0, f"layer {i}: the bf16 path needs a multiple of 32 filters in conv+BN layers (got {cout}); use precision='fp32'"
                 nbytes = L.ay_packed_weight_bytes(cpad, e["cin"], e["k"])
                 packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
                 check(L.ay_pack_conv_weights_bf16(ptr(w), ptr(packed), cout, cpad, e["cin"], e["k"], st), "ay_pack_conv_weights_bf16")
