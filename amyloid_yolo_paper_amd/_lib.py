@@ -94,6 +94,8 @@ _SIGS = {
     "ay_pack_dgrad_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_conv_wgrad_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "ay_conv_wgrad_bf16_acc": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
+    "ay_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ay_conv_wgrad_bf16_ws": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, C.c_size_t, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

@@ -25,6 +25,8 @@ struct WgradArgs {
     float* dw;
     int B, cin, cout, CIP, COP, hin, win, ho, wo;
     int nseg_x, total_segs;
+    float* slab;       // split-K partial filters [gridDim.z][dw_elems] (plain stores, summed in fixed order by wgrad_reduce_kernel);
+    size_t dw_elems;   // nullptr: the partial sums are added to dw with fp32 atomics
 };
 
 __device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2); }
@@ -194,7 +196,8 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
         }
     }
 
-    // ---- epilogue: fp32 atomics, coalesced.  D of one 16x16 tile: row (co) = 4*(lane>>4) + reg, col (ci) = lane & 15.
+    // ---- epilogue: the workgroup's partial filters go to its split-K slab (plain contiguous stores) or, without a workspace, to
+    // dW by fp32 atomics; either way coalesced.  D of one 16x16 tile: row (co) = 4*(lane>>4) + reg, col (ci) = lane & 15.
     // Adding straight from the accumulators would scatter every wave-instruction over 64 cache lines (measured: 17x
     // slower than contiguous atomics, and it was 90 % of this kernel).  Instead each wave transposes one co plane at a
     // time through its own 9 KiB of LDS into dW order [co][ci 16][tap] (144 contiguous floats per co row of this ci
@@ -216,13 +219,63 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
         for (int idx = lane; idx < 16 * ROW; idx += 64) {
             const int col = idx / ROW, rem = idx % ROW;  // rem = ci_local * KK2 + tap
             const int co = co_base + col, ci = ci0 + rem / KK2;
-            if (co < a.cout && ci < a.cin) atomicAdd(a.dw + ((size_t)co * a.cin + ci0) * KK2 + rem, stage[idx]);
+            if (co < a.cout && ci < a.cin) {
+                const size_t off = ((size_t)co * a.cin + ci0) * KK2 + rem;
+                if (a.slab)
+                    a.slab[(size_t)blockIdx.z * a.dw_elems + off] = stage[idx];
+                else
+                    atomicAdd(a.dw + off, stage[idx]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], s in ascending order: the same bits on every run.  Replaces ks x |dW| fp32
+// atomics (~1.3 TB/s chip-wide, 58 us of a 349-us launch at 128->256 3x3, B=32, 128^2) by plain stores + one streaming pass.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, size_t n, int ks, int accumulate) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 acc = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < ks; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * n + i);
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dw + i) = acc;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float acc = accumulate ? dw[j] : 0.f;
+            for (int s = 0; s < ks; ++s) acc += slab[(size_t)s * n + j];
+            dw[j] = acc;
+        }
+    }
+}
+
+static long long wgrad_split(const ay_conv_desc* d, int* cob, int* cib, long long* total) {
+    const int CIP = (d->cin + 15) / 16;
+    const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
+    *cob = (COP + 7) / 8;
+    *cib = (CIP + 3) / 4;
+    *total = (long long)d->batch * d->hout * ((d->wout + 31) / 32);
+    static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
+    long long ks = (wg_target + (long long)*cob * *cib - 1) / ((long long)*cob * *cib);   // ~1 workgroup per CU overall ...
+    if (ks > *total / 24) ks = *total / 24;                                            // ... but >= 24 K steps each (pipeline fill, epilogue)
+    if (ks > *total) ks = *total;
+    if (ks > 65535) ks = 65535;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+
 }  // namespace ay
+
+extern "C" size_t ay_conv_wgrad_workspace_bytes(const ay_conv_desc* d) {
+    if (!d) return 0;
+    int cob, cib;
+    long long total;
+    const long long ks = ay::wgrad_split(d, &cob, &cib, &total);
+    return (size_t)ks * d->cout * d->cin * d->ksize * d->ksize * sizeof(float);
+}
 
 extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream) {
     return ay_conv_wgrad_bf16_acc(d, x_blocked, dz_blocked, dw_oihw, 0, stream);
@@ -230,6 +283,11 @@ extern "C" int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, 
 
 extern "C" int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
                                       ay_stream_t stream) {
+    return ay_conv_wgrad_bf16_ws(d, x_blocked, dz_blocked, dw_oihw, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
+                                     void* workspace, size_t workspace_bytes, ay_stream_t stream) {
     using namespace ay;
     AY_CHECK_ARG(d && x_blocked && dz_blocked && dw_oihw, "ay_conv_wgrad_bf16: null");
     // cin need not be a multiple of 16: x is read as ceil(cin/16) planes (pad channels must be zero), dW rows ci >= cin are skipped
@@ -252,15 +310,15 @@ extern "C" int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_block
     const long long total = (long long)d->batch * d->hout * a.nseg_x;
     AY_CHECK_ARG(total > 0 && total < 0x7fffffffLL, "ay_conv_wgrad_bf16: too many segments");
     a.total_segs = (int)total;
-    const int cob = (a.COP + 7) / 8, cib = (a.CIP + 3) / 4;
-    static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
-    long long ks = (wg_target + (long long)cob * cib - 1) / ((long long)cob * cib);   // ~1 workgroup per CU overall (each pays ~300 KB of fp32 atomics at its end: 512 measured 3 % slower per step) ...
-    if (ks > total / 24) ks = total / 24;                                        // ... but >= 24 K steps each (pipeline fill, atomics)
-    if (ks > total) ks = total;
-    if (ks > 65535) ks = 65535;
-    if (ks < 1) ks = 1;
-    // the kernel ADDS its split-K partial sums (fp32 atomics): accumulate = 0 starts from zero, 1 from what dw holds
-    if (!accumulate && hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ksize * d->ksize, st) != hipSuccess) {
+    int cob, cib;
+    long long total2;
+    const long long ks = wgrad_split(d, &cob, &cib, &total2);
+    const size_t dw_elems = (size_t)d->cout * d->cin * d->ksize * d->ksize;
+    const bool slabs = workspace != nullptr && workspace_bytes >= (size_t)ks * dw_elems * sizeof(float);
+    a.slab = slabs ? (float*)workspace : nullptr;
+    a.dw_elems = dw_elems;
+    // without a workspace the kernel ADDS its split-K partial sums to dw (fp32 atomics): accumulate = 0 starts from zero
+    if (!slabs && !accumulate && hipMemsetAsync(dw_oihw, 0, sizeof(float) * dw_elems, st) != hipSuccess) {
         set_error("ay_conv_wgrad_bf16: memset failed");
         return AY_ERR_LAUNCH;
     }
@@ -272,5 +330,10 @@ extern "C" int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_block
     else
         hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), grid, block, 0, st, a);
     AY_CHECK_LAUNCH("wgrad_bf16_kernel");
+    if (slabs) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_elems + 1023) / 1024)), dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks,
+                           accumulate);
+        AY_CHECK_LAUNCH("wgrad_reduce_kernel");
+    }
     return AY_OK;
 }

@@ -448,8 +448,13 @@ def train_backward_bf16(model, stt, grad_scale=None):
             d_w = ConvDesc(B, cin, cout, hin, hin, hout, hout, k, e["stride"], 0, 0, rec["cpad"])  # cin = 3: rows ci >= 3 of the plane are skipped
         else:
             d_w = d
+        # split-K partial filters go to slabs in a workspace and are summed in a fixed order (reproducible; no fp32 atomics)
+        nws = L.ay_conv_wgrad_workspace_bytes(C.byref(d_w))
+        wws = ctx.buf.get("wgrad_ws")
+        if wws is None or wws.numel() < nws:
+            wws = ctx.buf["wgrad_ws"] = torch.empty(max(nws, 1 << 20), device=dev, dtype=torch.uint8)
         with _Timed(prof, "wgrad", _family(e)):
-            check(L.ay_conv_wgrad_bf16_acc(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, st), "ay_conv_wgrad_bf16")
+            check(L.ay_conv_wgrad_bf16_ws(C.byref(d_w), ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, ptr(wws), wws.numel(), st), "ay_conv_wgrad_bf16")
         if hook is not None:
             hook(i)
         # ---- data gradient: the forward kernel on flipped / transposed filters

@@ -271,6 +271,12 @@ int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int 
 int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream);
 int ay_conv_wgrad_bf16_acc(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
                            ay_stream_t stream);
+/* The same with a caller-owned workspace of ay_conv_wgrad_workspace_bytes(d) bytes: the split-K partial filters are written to
+ * slabs and summed in a fixed order by a second small kernel -- bit-identical results from run to run, and faster than the
+ * fp32 atomics of the forms above (which remain for callers without a workspace; a too small workspace falls back to them). */
+size_t ay_conv_wgrad_workspace_bytes(const ay_conv_desc* d);
+int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, int accumulate,
+                          void* workspace, size_t workspace_bytes, ay_stream_t stream);
 
 /* ---- inference plan: Darknet.forward (models.py:237-255) lowered to a flat op list ------------------------------
  * The host lowers the cfg graph once (which layers fuse, which routes fold into a loader) and hands the ops over; the

@@ -62,6 +62,20 @@ def test_wgrad_mfma(case):
     got, ref = dw.cpu(), w.grad
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), float((got - ref).abs().max() / ref.abs().max())
+    # with a workspace: split-K slabs summed in a fixed order -- same tolerance, bit-identical from run to run, and `accumulate`
+    # adds to what dW holds
+    nws = L.ay_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nws, 16), device=dev, dtype=torch.uint8)
+    runs = []
+    for _ in range(2):
+        dw2 = torch.full((cout, cin, k, k), float("nan"), device=dev)
+        check(L.ay_conv_wgrad_bf16_ws(C.byref(d), ptr(xb), ptr(dzb), ptr(dw2), 0, ptr(ws), ws.numel(), _lib.stream_ptr()), "wgrad_ws")
+        runs.append(dw2.cpu())
+    assert torch.equal(runs[0], runs[1]), "slab reduction is not reproducible"
+    assert float((runs[0] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    dw3 = torch.ones(cout, cin, k, k, device=dev)
+    check(L.ay_conv_wgrad_bf16_ws(C.byref(d), ptr(xb), ptr(dzb), ptr(dw3), 1, ptr(ws), ws.numel(), _lib.stream_ptr()), "wgrad_ws acc")
+    assert float((dw3.cpu() - 1.0 - runs[0]).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
 
 
 DGRAD_CASES = [(32, 64, 3, 1, 40), (128, 256, 3, 1, 13), (256, 128, 1, 1, 26), (1024, 24, 1, 1, 13), (64, 128, 3, 2, 32), (128, 256, 3, 2, 26)]
