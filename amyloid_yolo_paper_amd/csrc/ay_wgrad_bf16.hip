@@ -31,7 +31,10 @@ struct WgradArgs {
 
 __device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2); }
 
-template <int KS, int STRIDE>
+// SEGS: row segments per K step (and per barrier).  1x1 layers have 4 MFMAs per wave and segment: one segment per step left the
+// kernel barrier-bound (173 us per launch on average at B=32 / 1024^2 against ~70 us of HBM time); they take 4 segments per step
+// from a ring of 3 stages.
+template <int KS, int STRIDE, int SEGS = 1, int NBUF = 4>
 __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
@@ -44,13 +47,14 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int NPIECE = DZ_PIECES + X_PIECES;
     constexpr int PW = (NPIECE + 7) / 8;
     constexpr int X_BASE = DZ_PIECES * 1024;
-    constexpr int BUF_BYTES = NPIECE * 1024;
-    constexpr int NBUF = 4;
-    constexpr int DUMMY = NBUF * BUF_BYTES;
-    static_assert(NBUF * BUF_BYTES + 1024 <= 160 * 1024, "LDS");
-    static_assert(8 * 16 * 16 * KK2 * 4 <= NBUF * BUF_BYTES, "epilogue staging reuses the stage buffers");
+    constexpr int BUF_BYTES = NPIECE * 1024;            // one segment
+    constexpr int DUMMY = NBUF * SEGS * BUF_BYTES;
+    constexpr int PWS = PW * SEGS;                      // DMA pieces per wave and stage
+    static_assert(NBUF * SEGS * BUF_BYTES + 1024 <= 160 * 1024, "LDS");
+    static_assert(8 * 16 * 16 * KK2 * 4 <= NBUF * SEGS * BUF_BYTES, "epilogue staging reuses the stage buffers");
+    static_assert(NBUF == 3 || NBUF == 4, "ring depth");
 
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF * BUF_BYTES + 1024];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF * SEGS * BUF_BYTES + 1024];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,9 +64,10 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const unsigned lds_base = lds_addr_of(lds);
 
-    // segments of this workgroup: blockIdx.z, + gridDim.z, ...
-    int seg = blockIdx.z;
-    const int nstep = (a.total_segs - seg + (int)gridDim.z - 1) / (int)gridDim.z;
+    // segment groups (SEGS consecutive segments) of this workgroup: blockIdx.z, + gridDim.z, ...
+    const int seg = blockIdx.z;
+    const int total_groups = (a.total_segs + SEGS - 1) / SEGS;
+    const int nstep = (total_groups - seg + (int)gridDim.z - 1) / (int)gridDim.z;
     if (nstep <= 0) return;
 
     // ---- loader.  Which unit of a tile a lane carries in piece i (plane, row / tap row, pixel slot, channel half) does not depend
@@ -102,6 +107,8 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
         }
     }
     auto issue = [&](int sg, int buf) __attribute__((always_inline)) {
+        const bool seg_ok = sg < a.total_segs;  // the tail of the last group: every lane out of range, the buffer reads as zeros
+        if (!seg_ok) sg = 0;
         const int xs = sg % a.nseg_x;
         const int oy = (sg / a.nseg_x) % a.ho;
         const int b = sg / (a.nseg_x * a.ho);
@@ -117,11 +124,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
         for (int i = 0; i < PW; ++i) {
             const int qn = i * 8 + wave;  // wave-uniform piece id
             if (qn < DZ_PIECES) {
-                const unsigned vo = (ox0 + lane_dx[i] < a.wo) ? lane_off[i] : OOB;
+                const unsigned vo = (seg_ok && ox0 + lane_dx[i] < a.wo) ? lane_off[i] : OOB;
                 dma16_buf(rdz, vo, so_dz, lds_base + buf * BUF_BYTES + qn * 1024);
             } else if (qn < NPIECE) {
                 const int iy = oy * STRIDE + lane_dy[i], ix = ox0 * STRIDE + lane_dx[i];
-                const unsigned vo = (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) ? lane_off[i] : OOB;
+                const unsigned vo = (seg_ok && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) ? lane_off[i] : OOB;
                 dma16_buf(rx, vo, so_x, lds_base + buf * BUF_BYTES + qn * 1024);
             } else {
                 dma16_buf(rx, OOB, 0u, lds_base + DUMMY);   // keeps the per-wave piece count constant (counted vmcnt waits)
@@ -145,55 +152,62 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int t = 0; t < KK2; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    auto issue_stage = [&](int step, int slot) __attribute__((always_inline)) {
+        const int group = seg + step * (int)gridDim.z;
+#pragma unroll
+        for (int j = 0; j < SEGS; ++j) issue(group * SEGS + j, slot * SEGS + j);
+    };
+    auto wait_landed = [&](int ahead) __attribute__((always_inline)) {  // `ahead` stages issued beyond the one that must have landed
+        if (NBUF == 4 && ahead >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PWS) : "memory");
+        else if (ahead >= 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PWS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     // prologue: up to NBUF-1 stages in flight
     int issued = 0;
-    for (; issued < NBUF - 1 && issued < nstep; ++issued) issue(seg + issued * (int)gridDim.z, issued);
-    if (issued >= 3)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-    else if (issued == 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; issued < NBUF - 1 && issued < nstep; ++issued) issue_stage(issued, issued);
+    wait_landed(issued - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    int cur = 0, nxt = (NBUF - 1) % NBUF;
     for (int k = 0; k < nstep; ++k) {
-        const int cur = k & (NBUF - 1);
         if (issued < nstep) {
-            issue(seg + issued * (int)gridDim.z, issued & (NBUF - 1));
+            issue_stage(issued, nxt);
             ++issued;
         }
-        const uint8_t* L = lds + cur * BUF_BYTES;
-        bf16x8 af[COW];
+        if (++nxt == NBUF) nxt = 0;
 #pragma unroll
-        for (int j = 0; j < COW; ++j) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[0] + j * 1024));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[1] + j * 1024));
-            const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            __builtin_memcpy(&af[j], v, 16);
-        }
+        for (int sj = 0; sj < SEGS; ++sj) {
+            const uint8_t* L = lds + (cur * SEGS + sj) * BUF_BYTES;
+            bf16x8 af[COW];
 #pragma unroll
-        for (int t = 0; t < KK2; ++t) {
-            const int kh = t / KS, kw = t % KS;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][0] + kh * XW * 32));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][1] + kh * XW * 32));
-            const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            bf16x8 bfr;
-            __builtin_memcpy(&bfr, v, 16);
+            for (int j = 0; j < COW; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[0] + j * 1024));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[1] + j * 1024));
+                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                __builtin_memcpy(&af[j], v, 16);
+            }
 #pragma unroll
-            for (int j = 0; j < COW; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[j][t], 0, 0, 0);
+            for (int t = 0; t < KK2; ++t) {
+                const int kh = t / KS, kw = t % KS;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][0] + kh * XW * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][1] + kh * XW * 32));
+                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8 bfr;
+                __builtin_memcpy(&bfr, v, 16);
+#pragma unroll
+                for (int j = 0; j < COW; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[j][t], 0, 0, 0);
+            }
         }
         if (k + 1 < nstep) {
-            const int ahead = issued - (k + 1);  // stages issued beyond k: k+1 .. issued-1 ; k+1 must land, the rest may fly
-            if (ahead >= 3)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-            else if (ahead == 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_landed(issued - (k + 1) - 1);  // stages issued beyond k+1 may stay in flight
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        if (++cur == NBUF) cur = 0;
     }
 
     // ---- epilogue: the workgroup's partial filters go to its split-K slab (plain contiguous stores) or, without a workspace, to
@@ -252,12 +266,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+constexpr int WGRAD_SEGS_1X1 = 4;
+#ifndef AY_WGRAD_SEGS_3X3
+#define AY_WGRAD_SEGS_3X3 2
+#endif
+constexpr int WGRAD_SEGS_3X3 = AY_WGRAD_SEGS_3X3;   // 3x3 stride 1: 2 segments per K step from a ring of 3 stages (126 KiB)
+
 static long long wgrad_split(const ay_conv_desc* d, int* cob, int* cib, long long* total) {
     const int CIP = (d->cin + 15) / 16;
     const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
     *cob = (COP + 7) / 8;
     *cib = (CIP + 3) / 4;
     *total = (long long)d->batch * d->hout * ((d->wout + 31) / 32);
+    if (d->ksize == 1) *total = (*total + WGRAD_SEGS_1X1 - 1) / WGRAD_SEGS_1X1;   // K steps = groups of segments
+    if (d->ksize == 3 && d->stride == 1) *total = (*total + WGRAD_SEGS_3X3 - 1) / WGRAD_SEGS_3X3;
     static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
     long long ks = (wg_target + (long long)*cob * *cib - 1) / ((long long)*cob * *cib);   // ~1 workgroup per CU overall ...
     if (ks > *total / 24) ks = *total / 24;                                            // ... but >= 24 K steps each (pipeline fill, epilogue)
@@ -324,11 +346,11 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
     }
     dim3 grid(cob, cib, (unsigned)ks), block(512);
     if (d->ksize == 3 && d->stride == 1)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_SEGS_3X3 == 1 ? 4 : 3>), grid, block, 0, st, a);
     else if (d->ksize == 3)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1, 3>), grid, block, 0, st, a);
     AY_CHECK_LAUNCH("wgrad_bf16_kernel");
     if (slabs) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_elems + 1023) / 1024)), dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks,
