@@ -33,6 +33,7 @@ struct StemFusedArgs {
     const float* shift0;
     int leaky0;
     int H, W;
+    unsigned m_tx, m_tpi;   // v2: floor(2^32 / tiles_x), floor(2^32 / tiles per image) (0xffffffff for a divisor of 1)
     ConvArgs c1;            // layer 1 as a ConvArgs (src unused)
 };
 
@@ -271,6 +272,315 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: the same two layers, phases PIPELINED across two wave groups, with the LDS traffic and the instruction count cut.
+// v1's clock per item (8x32 outputs): tile DMA issue 0.9 us, stem phase 2.5 + 1.9 us at its barrier, layer-1 MFMA 1.2, epilogue
+// 0.5, tail 0.7 -- 7.8 us against 1.2 us of MFMA work.  What binds it is instruction issue (16 waves x ~1200 instructions per
+// item: per-lane 64-bit DMA addresses, item coordinates by integer division in every phase, single-value converts,
+// compare+select activations) and the LDS pipe (every layer-1 MFMA reads 2 KB of fragments: 32x32 register tiles have no
+// reuse; stride-2 pixel reads of 16-byte cells are 2-way bank conflicts).  Here:
+//   * an item is 4x32 outputs; the stem output has TWO slab sets in LDS; waves 0-7 (producers) compute the stem of item k into one
+//     set while waves 8-15 (consumers) run layer 1 + epilogue of item k-1 from the other; one barrier per item.  The two roles are
+//     separate loops, so each keeps its own constants in registers:
+//   * a consumer wave holds its 18 filter fragments of layer 1 (72 VGPRs) for the whole kernel: only pixel fragments come from LDS
+//   * stem slabs keep even and odd pixel columns apart, so the stride-2 reads of layer 1 are contiguous 16-byte cells
+//   * the image tile arrives by 16-byte buffer DMA (11 wave instructions per tile instead of 35 of 4 bytes; lanes outside the
+//     image read out of the descriptor's range = zeros): the window starts 4 columns left of the tile so that every piece is
+//     16-byte aligned in HBM (needs W % 4 == 0; other widths take v1).  Item coordinates come from one multiply-high division per
+//     item, computed when its tile is issued and kept in a register queue for the two later iterations that use them
+//   * the tile is stored [row][channel][column]: the 27 taps of a stem pixel are a 9 x 3 grid (rho = 3 kh + ci, kw) in it, and
+//     the K = 32 slots are ORDERED so that the 8 taps of lane half 1 are those of half 0 moved down 3 (K-step 0) or 2 (K-step
+//     1) grid rows: every LDS read of the stem is one per-lane base + an immediate; the 5 spare slots carry zero filters and
+//     re-read taps of the same or the next pixel row (finite whenever the image is).  Producers hold scale / shift in
+//     registers, LeakyReLU is max(t, slope t), two values per convert
+__global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s, int n_items) {
+    constexpr int TH = 4, TW = 32, BN = 64;
+    constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 9 x 65 stem pixels feed the tile
+    constexpr int S_PIX = SH * SW;                        // 585
+    constexpr int NBLK = (S_PIX + 31) / 32;               // 19 blocks of 32 stem pixels
+    constexpr int HALFW = TW + 1;                         // 33 even (and up to 33 odd) columns per slab row
+    constexpr int ROWP = 2 * HALFW;                       // slab row: [even columns 33][odd columns 33] cells of 16 B
+    constexpr int S_POS = SH * ROWP;                      // 594 cells; the lanes of the last block beyond pixel 584 write behind them
+    constexpr int S_POSP = S_POS + NBLK * 32 - S_PIX;     // 617
+    constexpr int IH = SH + 3;                            // 12 image rows 2*y0-2 .. (11 used + 1 that only zero filters see)
+    constexpr int IW = 72;                                // image columns 2*x0-4 .. 2*x0+67 (used: 2*x0-2 .. 2*x0+64)
+    constexpr int XOFF = 2;                               // window column of image column 2*x0-2
+    constexpr int ROW_PIECES = IW / 4;                    // 16-byte pieces per row
+    constexpr int IMG_PIECES = IH * 3 * ROW_PIECES;       // 648: [row][channel][column piece]
+    constexpr int IMG_DMAS = (IMG_PIECES + 63) / 64;      // 11 wave-wide DMA instructions per tile: one per wave (waves 11-15: none)
+    constexpr int IMG_BYTES = IMG_DMAS * 1024;
+    constexpr int NIB = 3;
+    constexpr int SLAB = 2 * S_POSP * 16;                 // one 16-channel chunk of stem output: [half][cell][8 ch]
+    constexpr int SET = 2 * SLAB;                         // both chunks
+    constexpr int OFF_SCRATCH = NIB * IMG_BYTES;          // where the DMA of a wave without a piece lands
+    constexpr int OFF_STEM = OFF_SCRATCH + 1024;
+    constexpr int OFF_SS1 = OFF_STEM + 2 * SET;
+    constexpr int LDS_BYTES = OFF_SS1 + 1024;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(IMG_DMAS <= 16, "one tile DMA per wave");
+    constexpr int MT = 1, NT = 1;
+    constexpr unsigned OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    __builtin_amdgcn_s_setprio(2);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const ConvArgs& a = s.c1;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int per_xcd = (n_items + 7) >> 3;
+    const int first = xcd * per_xcd;
+    const int last = min(first + per_xcd, n_items);
+    if (first + slot >= last) return;
+    const int nk = (last - (first + slot) + slots - 1) / slots;   // items of this workgroup: first + slot + k * slots, k < nk
+    const unsigned tiles_per_img = (unsigned)(a.tiles_x * a.tiles_y);
+    struct Coord { int b, y0, x0; };
+    auto coord_of = [&](int k) __attribute__((always_inline)) {   // item k of this workgroup -> image, tile origin
+        const unsigned it = (unsigned)(first + slot + k * slots);
+        unsigned b = __umulhi(it, s.m_tpi), r = it - b * tiles_per_img;
+        if (r >= tiles_per_img) ++b, r -= tiles_per_img;
+        unsigned ty = __umulhi(r, s.m_tx), tx = r - ty * (unsigned)a.tiles_x;
+        if (tx >= (unsigned)a.tiles_x) ++ty, tx -= (unsigned)a.tiles_x;
+        return Coord{(int)b, (int)ty * TH, (int)tx * TW};
+    };
+
+    if (tid < BN) {
+        float* ss1 = reinterpret_cast<float*>(lds + OFF_SS1);
+        ss1[tid] = a.scale[tid];
+        ss1[128 + tid] = a.shift[tid];
+    }
+    const unsigned lds_base = lds_addr_of(lds);
+    // this lane's piece of a tile: piece u = wave*64 + lane -> (row, channel, 4 columns)
+    const int pu = wave * 64 + lane;
+    const bool pu_ok = wave < IMG_DMAS && pu < IMG_PIECES;
+    const int pu_col = (pu % ROW_PIECES) * 4, pu_ci = (pu / ROW_PIECES) % 3, pu_row = pu / (ROW_PIECES * 3);
+    const int plane_elems = s.H * s.W;
+    const int pu_gofs = pu_ci * plane_elems + pu_row * s.W + pu_col;   // relative to image pixel (2*y0-2, 2*x0-4) of channel 0
+    auto issue_image = [&](const Coord& t, int slot_i) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.x) + (size_t)t.b * 3 * plane_elems, 0, 3 * plane_elems * 4, 0x00020000);
+        const int ybase = 2 * t.y0 - 2, xbase = 2 * t.x0 - 4;
+        const bool ok = pu_ok && (unsigned)(ybase + pu_row) < (unsigned)s.H && (unsigned)(xbase + pu_col) < (unsigned)s.W;
+        const unsigned vo = ok ? (unsigned)((pu_gofs + ybase * s.W + xbase) * 4) : OOB;
+        dma16_buf(rs, vo, 0u, lds_base + (wave < IMG_DMAS ? slot_i * IMG_BYTES + wave * 1024 : OFF_SCRATCH));
+    };
+
+    // ---- prologue: tiles of items 0 and 1 in flight, tile 0 landed.  Coordinate queue: cA = item k, cB = item k+1 at loop entry
+    Coord cA = coord_of(0), cB = cA;
+    issue_image(cA, 0);
+    if (nk > 1) {
+        cB = coord_of(1);
+        issue_image(cB, 1);
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#ifdef AY_PHASE_CLOCK
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_last = wall_clock64();
+#define STEM2_TICK(w0, kk)                                   \
+    if (wave == w0) {                                        \
+        const unsigned long long t_ = wall_clock64();        \
+        tk[kk] += t_ - tk_last;                              \
+        tk_last = t_;                                        \
+    }
+#else
+#define STEM2_TICK(w0, kk)
+#endif
+
+    // iteration k = 0 .. nk: producers compute the stem of item k into slab set k & 1 (from tile buffer k % 3), consumers run layer 1
+    // of item k-1 from set (k-1) & 1; the tile of item k+2 is issued by every wave into buffer (k+2) % 3 = the one item k-1 was
+    // read from in iteration k-1.  Both loops pass the same nk + 1 barriers.
+    if (wave < 8) {
+        // tap grid of a stem pixel in the tile: rho = 3 kh + ci (9 rows of IW floats), kw.  K slots (tap = rho*3 + kw, -1: zero filter):
+        //   step 0, half 0: rows 0,1 and (2,0) (2,1); half 1: the same 3 rows down
+        //   step 1, half 0: rows 6,7 and (2,2) (5,2); half 1: the same 2 rows down = row 8 (real), row 9, (4,2), (7,2) (zero filters)
+        auto slotA = [](int e) constexpr { return e; };                                        // taps 0..7 = rows 0,1,(2,0),(2,1)
+        auto slotC = [](int e) constexpr { return e < 6 ? 18 + e : (e == 6 ? 2 * 3 + 2 : 5 * 3 + 2); };
+        auto goff = [](int t) constexpr { return (t / 3) * IW + t % 3; };                       // float offset of grid tap t
+        auto kref = [](int t) constexpr { return ((t / 3) % 3) * 9 + (t / 9) * 3 + t % 3; };   // its index ci*9 + kh*3 + kw in w0
+        bf16x8 wa[2];
+        {
+            const uint16_t* wr = s.w0 + c * 32;   // filters of output channel c
+            uint16_t w0v[8], w1v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                w0v[e] = hh ? wr[kref(slotA(e) + 9)] : wr[kref(slotA(e))];
+                const int td = slotC(e) + 6;      // half 1 of step 1: real only for grid row 8
+                w1v[e] = hh ? (td / 3 == 8 ? wr[kref(td)] : (uint16_t)0) : wr[kref(slotC(e))];
+            }
+            wa[0] = __builtin_bit_cast(bf16x8, make_uint4(w0v[0] | (unsigned)w0v[1] << 16, w0v[2] | (unsigned)w0v[3] << 16,
+                                                           w0v[4] | (unsigned)w0v[5] << 16, w0v[6] | (unsigned)w0v[7] << 16));
+            wa[1] = __builtin_bit_cast(bf16x8, make_uint4(w1v[0] | (unsigned)w1v[1] << 16, w1v[2] | (unsigned)w1v[3] << 16,
+                                                           w1v[4] | (unsigned)w1v[5] << 16, w1v[6] | (unsigned)w1v[7] << 16));
+        }
+        // stem scale / shift of this lane's 16 output channels 8q + 4hh + 2j2 (+1)
+        f32x2 sc0[8], sh0[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int ch = 8 * q + 4 * hh + 2 * j2;
+                sc0[q * 2 + j2] = f32x2{s.scale0[ch], s.scale0[ch + 1]};
+                sh0[q * 2 + j2] = f32x2{s.shift0[ch], s.shift0[ch + 1]};
+            }
+        const float slope0 = s.leaky0 ? 0.1f : 1.0f;
+        // this wave's blocks: wave, wave + 8 and (waves 0-2) wave + 16; per lane: tile offsets of its pixel (K-step 0 / 1 bases), slab cell
+        int pbase0[3], pbase1[3], pcell[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int P = (wave + 8 * j) * 32 + c;
+            const int sy = P / SW, sx = P - sy * SW;
+            const bool inside = P < S_PIX;
+            const int px = inside ? sy * 3 * IW + sx + XOFF : XOFF;
+            pbase0[j] = px + hh * 3 * IW;
+            pbase1[j] = px + hh * 2 * IW;
+            pcell[j] = (inside ? sy * ROWP + (sx & 1) * HALFW + (sx >> 1) : S_POS + (P - S_PIX)) * 16 + hh * 8;
+        }
+        for (int k = 0; k <= nk; ++k) {
+            const bool issue2 = k + 2 < nk;
+            Coord cC = cB;
+            if (issue2) {
+                cC = coord_of(k + 2);
+                issue_image(cC, (k + 2) % NIB);
+            }
+            STEM2_TICK(0, 0)
+            if (k < nk && !AY_DBGBIT(a, 16)) {
+                const int y0 = cA.y0, x0 = cA.x0;
+                const float* img = reinterpret_cast<const float*>(lds + (k % NIB) * IMG_BYTES);
+                uint8_t* set = lds + OFF_STEM + (k & 1) * SET;
+                // every stem pixel of the tile is a real one unless the tile touches the image border
+                const bool interior = 2 * y0 - 1 >= 0 && 2 * y0 - 1 + SH <= s.H && 2 * x0 - 1 >= 0 && 2 * x0 - 1 + SW <= s.W;
+                auto block = [&](int j) __attribute__((always_inline)) {
+                    const float* p0 = img + pbase0[j];
+                    const float* p1 = img + pbase1[j];
+                    f32x2 v0[4], v1[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        v0[jj] = f32x2{p0[goff(slotA(2 * jj))], p0[goff(slotA(2 * jj + 1))]};
+                        v1[jj] = f32x2{p1[goff(slotC(2 * jj))], p1[goff(slotC(2 * jj + 1))]};
+                    }
+                    const uint4 b0 = make_uint4(pack2bf2(v0[0]), pack2bf2(v0[1]), pack2bf2(v0[2]), pack2bf2(v0[3]));
+                    const uint4 b1 = make_uint4(pack2bf2(v1[0]), pack2bf2(v1[1]), pack2bf2(v1[2]), pack2bf2(v1[3]));
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                    bool real = true;
+                    if (!interior) {   // border tile: pixels outside the image are the zero padding of layer 1
+                        const int P = (wave + 8 * j) * 32 + c;
+                        const int sy = P / SW, sx = P - sy * SW;
+                        const int gy = 2 * y0 - 1 + sy, gx = 2 * x0 - 1 + sx;
+                        real = gy >= 0 && gy < s.H && gx >= 0 && gx < s.W;
+                    }
+                    uint8_t* dst = set + pcell[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 t0 = leaky2(f32x2{acc[4 * q], acc[4 * q + 1]} * sc0[2 * q] + sh0[2 * q], slope0);
+                        const f32x2 t1 = leaky2(f32x2{acc[4 * q + 2], acc[4 * q + 3]} * sc0[2 * q + 1] + sh0[2 * q + 1], slope0);
+                        uint2 o = make_uint2(pack2bf2(t0), pack2bf2(t1));
+                        if (!real) o = make_uint2(0u, 0u);
+                        *reinterpret_cast<uint2*>(dst + (q >> 1) * SLAB + (q & 1) * S_POSP * 16) = o;
+                    }
+                };
+                block(0);
+                block(1);
+                if (wave + 16 < NBLK) block(2);
+            }
+            STEM2_TICK(0, 1)
+            // the tile of item k+1 must have landed (issued in iteration k-1 or the prologue); younger: the DMA of tile k+2 if issued
+            if (issue2)
+                asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cA = cB;
+            cB = cC;
+            STEM2_TICK(0, 2)
+#ifdef AY_PHASE_CLOCK
+            if (wave == 0) ++tk[6];
+#endif
+        }
+    } else {
+        // layer 1: 8 waves = 2 (32-channel halves) x 4 (output rows); filters [chunk][tap][half][64][8] straight from HBM into registers
+        const int cwv = wave & 7;
+        const int wn = cwv & 3, wm = cwv >> 2;
+        bf16x8 wf[18];
+#pragma unroll
+        for (int n = 0; n < 18; ++n)
+            wf[n] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(n * 2 + hh) * BN + wm * 32 + c) * 16);
+        // cell of input pixel (row 2*wn + kh, column 2*c + kw): (2*wn + kh)*ROWP + (kw & 1)*HALFW + c + (kw >> 1)
+        const int pb = (hh * S_POSP + (wn * 2) * ROWP + c) * 16;
+        Coord cP = cA;   // item k-1
+        for (int k = 0; k <= nk; ++k) {
+            const bool issue2 = k + 2 < nk;
+            Coord cC = cB;
+            if (issue2) {
+                cC = coord_of(k + 2);
+                issue_image(cC, (k + 2) % NIB);
+            }
+            bool stored = false;
+            STEM2_TICK(8, 3)
+            if (k >= 1 && !AY_DBGBIT(a, 32)) {
+                const uint8_t* set = lds + OFF_STEM + ((k - 1) & 1) * SET;
+                f32x16 acc1[MT][NT];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[0][0][r] = 0.f;
+                bf16x8 fb[2][3];   // pixel fragments one filter row ahead of the MFMAs that use them
+                auto load_row = [&](int n, int sl) __attribute__((always_inline)) {
+                    const int ch = n / 3, kh = n % 3;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        fb[sl][kw] = *reinterpret_cast<const bf16x8*>(set + ch * SLAB + pb + (kh * ROWP + (kw & 1) * HALFW + (kw >> 1)) * 16);
+                };
+                load_row(0, 0);
+#pragma unroll
+                for (int n = 0; n < 6; ++n) {
+                    if (n + 1 < 6) load_row(n + 1, (n + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n * 3 + kw], fb[n & 1][kw], acc1[0][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                STEM2_TICK(8, 4)
+                ResRegs<MT, NT> rr;
+                conv_epilogue<BN, MT, NT, TW, false, false, false, 2>(a, acc1, rr, cP.b, 0, wm, wn, c, hh, cP.y0, cP.x0,
+                                                                      reinterpret_cast<const float*>(lds + OFF_SS1));
+                stored = (cP.y0 + wn) < a.hout;
+            }
+            STEM2_TICK(8, 5)
+            // as for the producers, plus the two output stores of this wave's item (younger than both DMAs)
+            if (issue2) {
+                if (stored)
+                    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            } else {
+                if (stored)
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cP = cA;
+            cA = cB;
+            cB = cC;
+            STEM2_TICK(8, 7)
+        }
+    }
+#ifdef AY_PHASE_CLOCK
+    if ((wave == 0 || wave == 8) && lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_stem_ticks[k], tk[k]);
+#endif
+}
+
 }  // namespace ay
 
 extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const float* scale0, const float* shift0, int leaky0,
@@ -301,11 +611,16 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     a.win = w;
     a.hout = h / 2;
     a.wout = w / 2;
+    static const int v2_env = getenv("AY_STEM_V2") ? atoi(getenv("AY_STEM_V2")) : 1;   // 0: the serial-phase kernel (8x32 items)
+    const bool v2 = v2_env && w % 4 == 0 && (reinterpret_cast<uintptr_t>(x_nchw) & 15) == 0 && 3LL * h * w * 4 < 0x7fffffffLL;
     a.tiles_x = (a.wout + 31) / 32;
-    a.tiles_y = (a.hout + 7) / 8;
+    a.tiles_y = v2 ? (a.hout + 3) / 4 : (a.hout + 7) / 8;
     a.n_cgroups = 1;
+    auto magic = [](unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ULL / d); };
+    s.m_tx = magic((unsigned)a.tiles_x);
+    s.m_tpi = magic((unsigned)(a.tiles_x * a.tiles_y));
     a.leaky = leaky1;
-    a.dbg = 0;
+    a.dbg = getenv("AY_DBG") ? atoi(getenv("AY_DBG")) : 0;   // read only by the instrumented build (AY_DBGBIT)
     a.stagger = 0;
     a.deal = nullptr;
     a.canvas_gx = 0;
@@ -316,7 +631,10 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     const int per_xcd = (int)((n_items + 7) / 8);
     const int cu_slots = conv_num_cus() / 8;
     dim3 grid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
-    hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
+    if (v2)
+        hipLaunchKernelGGL(stem_s2_fused_v2_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
+    else
+        hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
     AY_CHECK_LAUNCH("stem_s2_fused_kernel");
 #ifdef AY_PHASE_CLOCK
     if (getenv("AY_DBG") && (atoi(getenv("AY_DBG")) & 8)) {
@@ -324,7 +642,10 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
         (void)hipStreamSynchronize(S(stream));
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stem_ticks), sizeof(t));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stem_ticks), z, sizeof(z));
-        if (t[6])
+        if (t[6] && v2)
+            fprintf(stderr, "[ay stem v2] per iteration (us): producer issue %.2f, stem %.2f, wait %.2f | consumer issue %.2f, layer-1 %.2f, epilogue %.2f, wait %.2f\n",
+                    t[0] * 0.01 / t[6], t[1] * 0.01 / t[6], t[2] * 0.01 / t[6], t[3] * 0.01 / t[6], t[4] * 0.01 / t[6], t[5] * 0.01 / t[6], t[7] * 0.01 / t[6]);
+        else if (t[6])
             fprintf(stderr, "[ay stem] per item (us): dma issue %.2f, stem MFMA %.2f, barrier %.2f, layer-1 MFMA %.2f, epilogue %.2f, tail wait %.2f\n",
                     t[0] * 0.01 / t[6], t[1] * 0.01 / t[6], t[2] * 0.01 / t[6], t[3] * 0.01 / t[6], t[4] * 0.01 / t[6], t[5] * 0.01 / t[6]);
     }
