@@ -204,6 +204,10 @@ __device__ unsigned g_deal[DEAL_STREAMS * DEAL_SETS][16];
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
     static_assert(!CANVAS || !CAT, "canvas tiling: single-source layers");
+    // KS == 2: a 2x2 window with offsets {0, +1} (no padding on the low side) whose channel-group index carries an output pixel
+    // parity class; see ConvArgs::w_class_stride
+    constexpr bool UP2 = (KS == 2);
+    static_assert(!UP2 || (STRIDE == 1 && !CAT && !CANVAS), "2x2-window kernels: stride 1, plain tiles");
     static_assert(!CAT || (KS == 1 && STRIDE == 1), "route + upsample folding exists for the 1x1 kernel");
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
@@ -314,13 +318,18 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     bool ld_done = false;
     const float* ld_ss = nullptr;  // per-lane source of the scale/shift piece (nullptr: zero page)
     auto setup_loader = [&](int it) __attribute__((always_inline)) {
-        const int cg = it % a.n_cgroups;
+        int cg = it % a.n_cgroups;
         const int pt = it / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
         ld_src = a.src + (size_t)b * ((a.cin - (CAT ? a.c1 : 0)) / 16) * in_plane;
         if constexpr (CAT) ld_src1 = a.src1 + (size_t)b * (a.c1 / 16) * in_plane1;
-        ld_w = a.w + (size_t)cg * BN * 16;
+        const uint8_t* wbase = a.w;
+        if constexpr (UP2) {
+            wbase += (size_t)(cg & 3) * a.w_class_stride;
+            cg >>= 2;
+        }
+        ld_w = wbase + (size_t)cg * BN * 16;
         // lanes 0..BN/4-1 fetch 4 scales each, lanes 32..32+BN/4-1 the shifts: LDS image [scale | pad to 128][shift]
         if constexpr (SSP == 1)
             ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
@@ -438,7 +447,9 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     if (clk) tk_begin = wall_clock64();
     while (true) {
         if (clk) tk0 = wall_clock64();
-        const int cg = item % a.n_cgroups;
+        int cg = item % a.n_cgroups;
+        const int cls = UP2 ? (cg & 3) : 0;
+        if constexpr (UP2) cg >>= 2;
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
-            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES, CANVAS>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES, CANVAS, UP2>(a, rr, b, cg, wm, wn, c, hh, y0, x0, cls);
 
             const uint8_t* L = lds + cur * BUF_BYTES;
             constexpr int NSTEP = NK * KK2;
@@ -524,8 +535,8 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         }
         int fetched = last;
         if (MAILBOX && tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
-                                                                       reinterpret_cast<const float*>(lds + SS_BASE + par * SSR));
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS, UP2>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+                                                                            reinterpret_cast<const float*>(lds + SS_BASE + par * SSR), cls);
         if (MAILBOX && tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -661,6 +672,7 @@ static void fill_args(ConvArgs& a, const ay_conv_desc* d, const void* src, const
     a.src1 = nullptr;
     a.c1 = 0;
     a.canvas_gx = 0;
+    a.w_class_stride = 0;
 }
 
 // RING = false: the 4-wave register-staged kernel (fp32-output heads, cout_pad not a multiple of 64); RING = true: the persistent
@@ -771,6 +783,41 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     return AY_OK;
 }
 
+// Data gradient of a 3x3 stride-2 convolution as four 2x2-window stride-1 convolutions over dz, one per parity class of the
+// output pixel: the ring kernel with KS = 2, classes riding in the channel-group index (class fastest, so the four classes of a
+// tile -- which interleave in the same 128-byte lines of dx -- run side by side)
+template <int BN, int WM, int WN, int NK>
+static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w, const float* scale, const float* shift,
+                           const void* residual, void* dx, int cin_pad, hipStream_t st) {
+    constexpr int TH = 8, TW = 32;
+    ay_conv_desc dd = *d;
+    dd.cin = d->cout_pad;     // reduction over dz's channel planes
+    dd.cout = d->cin;
+    dd.cout_pad = cin_pad;
+    dd.hin = d->hout, dd.win = d->wout;
+    dd.ksize = 2, dd.stride = 1, dd.leaky = 0, dd.out_f32 = 0;
+    ConvArgs a;
+    fill_args(a, &dd, dz, w, scale, shift, residual, dx, TH, TW, BN);
+    a.n_cgroups = 4 * (cin_pad / BN);
+    a.w_class_stride = (unsigned)((size_t)(d->cout_pad / 16) * 4 * 2 * cin_pad * 16);
+    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        set_error("dgrad grid out of range (%lld)", nblk);
+        return AY_ERR_ARG;
+    }
+    a.deal = next_deal_set(st);
+    const int per_xcd = (int)((nblk + 7) / 8);
+    const int cu_slots = conv_num_cus() / 8;
+    dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots))), block(512);
+    constexpr int NBUF = ring_depth<2, 1, BN, TH, TW, NK>();
+    if (residual)
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
+    else
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
+    AY_CHECK_LAUNCH("conv_bf16_ring_kernel(dgrad s2)");
+    return AY_OK;
+}
+
 }  // namespace ay
 
 extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
@@ -783,6 +830,23 @@ extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_h
     AY_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->cout, "ay_conv1x1_cat_fwd_bf16: cout_pad %d (multiple of 128)", d->cout_pad);
     AY_CHECK_ARG(d->hin % 2 == 0 && d->win % 2 == 0 && d->hout == d->hin && d->wout == d->win, "ay_conv1x1_cat_fwd_bf16: even sizes");
     return launch_ring1x1<128, 2, 4, true>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
+}
+
+extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, const void* w_s2_packed, const float* ones, const float* zeros,
+                                     const void* residual, void* dx, int cin_pad, ay_stream_t stream) {
+    using namespace ay;
+    AY_CHECK_ARG(d && dz && w_s2_packed && ones && zeros && dx, "ay_conv_dgrad_s2_bf16: null argument");
+    AY_CHECK_ARG(d->ksize == 3 && d->stride == 2 && d->hin == 2 * d->hout && d->win == 2 * d->wout,
+                 "ay_conv_dgrad_s2_bf16: a 3x3 stride-2 convolution of an even-sized input (%dx%d -> %dx%d)", d->hin, d->win, d->hout, d->wout);
+    AY_CHECK_ARG(d->cout_pad % 32 == 0 && cin_pad % 32 == 0 && cin_pad >= d->cin, "ay_conv_dgrad_s2_bf16: channels %d(%d) <- %d", d->cin, cin_pad,
+                 d->cout_pad);
+    AY_CHECK_ARG((long long)d->hin * d->win * 2 * cin_pad < (1ll << 31), "ay_conv_dgrad_s2_bf16: one image of dx exceeds 2 GiB");
+    hipStream_t st = S(stream);
+    const int kin = d->cout_pad;
+    if (cin_pad % 128 == 0 && kin % 32 == 0) return launch_dgrad_s2<128, 2, 4, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    if (cin_pad % 64 == 0 && kin % 32 == 0) return launch_dgrad_s2<64, 1, 8, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    if (kin % 64 == 0) return launch_dgrad_s2<32, 1, 8, 4>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    return launch_dgrad_s2<32, 1, 8, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
 }
 
 extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,

@@ -34,6 +34,11 @@ struct ConvArgs {
     // below, one zero column / row between neighbours (their shared halo) -- and every tile pixel maps to (image, y, x) or to
     // nothing.  Stride-1 same-size convolutions only; per-lane image offsets are 32-bit (host-checked).
     int canvas_gx;
+    // 2x2-window kernels (KS == 2: the data gradient of a 3x3 stride-2 convolution, one stride-1 sub-convolution per output pixel
+    // parity class (py, px)): the item's channel-group index carries the class in its two low bits, the class's filter image
+    // lies w_class_stride bytes after the previous one, and output pixel (oy, ox) of the class grid is pixel (2 oy + py, 2 ox + px)
+    // of the [2 hout][2 wout] output planes
+    unsigned w_class_stride;
 };
 
 // canvas pixel -> image pixel; false: gutter / beyond the batch (reads as zero, is never stored)
@@ -73,12 +78,12 @@ struct ResRegs {
     uint4 r[MT][NT][2];
 };
 
-template <int BN, int MT, int NT, int TW, bool HAS_RES, bool CANVAS = false>
+template <int BN, int MT, int NT, int TW, bool HAS_RES, bool CANVAS = false, bool UP2 = false>
 __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT, NT>& rr, int b, int cg, int wm, int wn, int c,
-                                                  int hh, int y0, int x0) {
+                                                  int hh, int y0, int x0, int cls = 0) {
     if constexpr (HAS_RES) {
         const int CP = a.cout_pad;
-        const size_t out_plane_px = (size_t)a.hout * a.wout;
+        const size_t out_plane_px = (size_t)a.hout * a.wout * (UP2 ? 4 : 1);
         const int cbase = cg * BN + wm * MT * 32;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -90,7 +95,7 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
             if constexpr (CANVAS) {
                 if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;  // any valid address
             }
-            const size_t pix = (size_t)oy * a.wout + ox;
+            const size_t pix = UP2 ? (size_t)(2 * oy + (cls >> 1)) * (2 * a.wout) + 2 * ox + (cls & 1) : (size_t)oy * a.wout + ox;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -119,11 +124,17 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 // The IEEE operations and their order are unchanged (no contraction), so are the results, bit for bit.
 // CANVAS: the tile lies on the canvas of ConvArgs::canvas_gx (a compile-time switch: as run-time branches the mapping code
 // cost the kernels that never use it SGPR spills -- the fused block went from 1.36 to 1.81 ms)
-template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0, bool CANVAS = false>
+template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0, bool CANVAS = false,
+          bool UP2 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
-                                              int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr) {
+                                              int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr, int cls = 0) {
+    static_assert(!UP2 || (!CANVAS && !OUT_F32), "parity-class output: plain bf16 tiles");
     const int CP = a.cout_pad;
-    const size_t out_plane_px = (size_t)a.hout * a.wout;
+    const size_t out_plane_px = (size_t)a.hout * a.wout * (UP2 ? 4 : 1);
+    // pixel index of output (oy, ox) inside a plane
+    auto opix = [&](int oy, int ox) __attribute__((always_inline)) {
+        return UP2 ? (unsigned)(2 * oy + (cls >> 1)) * (unsigned)(2 * a.wout) + 2 * ox + (cls & 1) : (unsigned)oy * a.wout + ox;
+    };
     const int cbase = cg * BN + wm * MT * 32;
     const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
     constexpr int SHO = BN > 128 ? BN : 128;  // float offset of the shifts in the LDS scale/shift image
@@ -161,7 +172,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         if constexpr (CANVAS) {
             if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;
         }
-        const unsigned pix_off = ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bb * img_bytes;
+        const unsigned pix_off = opix(oy, ox) * 32u + hh * 16u + (unsigned)bb * img_bytes;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes);
@@ -179,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         int oy = y0 + p / TW, ox = x0 + p % TW, bn = b;  // bn: the image of this lane's pixel (canvas mode: per lane)
         bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
         if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
-        const size_t pix = (size_t)oy * a.wout + ox;
+        const size_t pix = opix(oy, ox);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int t = n * MT + m;
@@ -263,7 +274,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             int oy = y0 + p / TW, ox = x0 + p % TW, bn = 0;
             bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
             if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
-            const unsigned vo = ok ? ((unsigned)oy * a.wout + ox) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
+            const unsigned vo = ok ? opix(oy, ox) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -326,6 +326,33 @@ __global__ void pack_dgrad_weights_kernel(const float* __restrict__ w, uint16_t*
     }
 }
 
+// filter images of the four parity classes of a stride-2 data gradient: [class py*2+px][cout_pad/16][window tap oy*2+ox][half][cin_pad][8];
+// window row oy of class py holds filter row kh: py = 0: oy 0 -> kh 1, oy 1 -> none; py = 1: oy 0 -> kh 2, oy 1 -> kh 0 (columns alike)
+__global__ void pack_dgrad_s2_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cout_pad, int cin,
+                                             int cin_pad) {
+    const size_t per_class = (size_t)(cout_pad / 16) * 4 * 2 * cin_pad * 8;
+    const size_t total = 4 * per_class;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_class);
+        size_t t = i % per_class;
+        const int j = (int)(t % 8);
+        t /= 8;
+        const int ci = (int)(t % cin_pad);
+        t /= cin_pad;
+        const int half = (int)(t % 2);
+        t /= 2;
+        const int tap = (int)(t % 4);
+        const int chunk = (int)(t / 4);
+        const int co = chunk * 16 + half * 8 + j;
+        const int py = cls >> 1, px = cls & 1, oy = tap >> 1, ox = tap & 1;
+        const int kh = py ? (oy ? 0 : 2) : (oy ? -1 : 1);
+        const int kw = px ? (ox ? 0 : 2) : (ox ? -1 : 1);
+        float v = 0.f;
+        if (co < cout && ci < cin && kh >= 0 && kw >= 0) v = w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+        out[i] = f2bf(v);
+    }
+}
+
 // chunks of one (image, plane) slice: every thread gets about two rounds of BN_UNROLL units where the plane allows, and the whole
 // grid stays below ~16k workgroups (each sums workgroup ends with one fp64 atomic per channel)
 static inline int bn_chunks(int batch, int planes, int HW) {
@@ -421,6 +448,19 @@ extern "C" int ay_zero_insert_bf16(const void* in, void* out, int batch, int cha
     const size_t units = (size_t)planes * ho * wo * 2;
     hipLaunchKernelGGL(zero_insert_kernel, dim3(gridu(units)), dim3(256), 0, S(stream), (const uint4*)in, (uint4*)out, planes, h, w, ho, wo);
     AY_CHECK_LAUNCH("zero_insert_kernel");
+    return AY_OK;
+}
+
+extern "C" size_t ay_packed_dgrad_s2_weight_bytes(int cout_pad, int cin_pad) {
+    return (size_t)4 * (cout_pad / 16) * 4 * 2 * cin_pad * 8 * 2;
+}
+
+extern "C" int ay_pack_dgrad_s2_weights_bf16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int cin_pad, ay_stream_t stream) {
+    AY_CHECK_ARG(w_oihw && packed && cin_pad >= cin && cin_pad % 32 == 0 && cout_pad >= cout && cout_pad % 16 == 0, "ay_pack_dgrad_s2_weights_bf16: bad args");
+    const size_t total = (size_t)4 * (cout_pad / 16) * 4 * 2 * cin_pad * 8;
+    hipLaunchKernelGGL(pack_dgrad_s2_weights_kernel, dim3(gridu(total)), dim3(256), 0, S(stream), w_oihw, (uint16_t*)packed, cout, cout_pad, cin,
+                       cin_pad);
+    AY_CHECK_LAUNCH("pack_dgrad_s2_weights_kernel");
     return AY_OK;
 }
 

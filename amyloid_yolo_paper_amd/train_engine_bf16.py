@@ -18,12 +18,16 @@ shape-keyed pool for the backward's gradient tensors, which are handed back as s
 optimiser step (when a parameter's version or ``parallel.WEIGHT_EPOCH`` changes), not once per forward.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 from ._lib import ConvDesc, check, ptr
 from .train_engine import METRIC_KEYS, _ws
+
+# AY_S2_DGRAD=0: data gradient of the stride-2 layers as a stride-1 convolution over the zero-inserted output gradient (round 1)
+_S2_DGRAD = os.environ.get("AY_S2_DGRAD", "1") != "0"
 
 
 def _pad(v, m):
@@ -155,8 +159,13 @@ def _pack_weights(model, ctx):
         rec.update(fwd=fwd, cpad=cpad, cin_eff=cin_eff)
         if e["src"] >= 0:
             cin_pad = _pad(cin, 32)
-            dg = ctx.get(("pkd", i), ((cpad // 16) * k * k * 2 * cin_pad * 8 * 2,), torch.uint8, zero=True)  # rows of the pad planes stay zero
-            check(L.ay_pack_dgrad_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cin, cin_pad, k, st), "ay_pack_dgrad_weights_bf16")
+            if e["stride"] == 2 and _S2_DGRAD:
+                # four parity-class filter images for ay_conv_dgrad_s2_bf16 (no zero insertion)
+                dg = ctx.get(("pkd", i), (L.ay_packed_dgrad_s2_weight_bytes(cpad, cin_pad),), torch.uint8)
+                check(L.ay_pack_dgrad_s2_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cpad, cin, cin_pad, st), "ay_pack_dgrad_s2_weights_bf16")
+            else:
+                dg = ctx.get(("pkd", i), ((cpad // 16) * k * k * 2 * cin_pad * 8 * 2,), torch.uint8, zero=True)  # rows of the pad planes stay zero
+                check(L.ay_pack_dgrad_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cin, cin_pad, k, st), "ay_pack_dgrad_weights_bf16")
             rec.update(dgrad=dg, cin_pad=cin_pad)
     ctx.packed_sig = sig
     return ctx.packed
@@ -466,6 +475,16 @@ def train_backward_bf16(model, stt, grad_scale=None):
         cin_pad = pk["cin_pad"]
         kin = rec["cpad"]                       # channels of dz's planes (>= cout, multiple of 32)
         src_dz = dz
+        if e["stride"] == 2 and _S2_DGRAD:
+            # four stride-1 sub-convolutions of dz with a 2x2 window, one per parity class of the input pixel
+            ones, zeros = model._unit(cin_pad, dev)
+            first = j not in dval
+            if first:
+                dval[j] = pool.get((B, cin_pad // 16, hin, hin, 16))
+            check(L.ay_conv_dgrad_s2_bf16(C.byref(d), ptr(dz), ptr(pk["dgrad"]), ptr(ones), ptr(zeros), None if first else ptr(dval[j]), ptr(dval[j]),
+                                          cin_pad, st), "ay_conv_dgrad_s2_bf16")
+            pool.put(dz)
+            continue
         if e["stride"] == 2:
             up = pool.get((B, kin // 16, hin, hin, 16))
             check(L.ay_zero_insert_bf16(ptr(dz), ptr(up), B, kin, hout, hout, hin, hin, st), "ay_zero_insert_bf16")

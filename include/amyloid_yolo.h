@@ -266,6 +266,18 @@ int ay_zero_insert_bf16(const void* in, void* out, int batch, int channels, int 
 /* filters that make ay_conv_fwd_bf16 compute the data gradient: W'[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw], packed
  * [ceil(cout/16)][k*k][2][cin_pad][8]; use with desc{cin=ceil16(cout), cout=cin, cout_pad=cin_pad, stride 1}. */
 int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int cin, int cin_pad, int ksize, ay_stream_t stream);
+/* Data gradient of a 3x3 stride-2 convolution (the reference gets it from autograd: loss.backward(), train.py:113, through
+ * nn.Conv2d(stride=2), models.py:33-41) WITHOUT zero insertion: output pixel (y, x) only receives the filter taps with
+ * (y + 1 - kh) and (x + 1 - kw) even, so each parity class (y & 1, x & 1) of dx is a stride-1 convolution of dz with a
+ * 2x2 window of 1, 2, 2 or 4 live taps -- 16 tap slots per dz pixel instead of the 36 of the zero-inserted form, and dz is
+ * read at its own (quarter) size.  `d` is the FORWARD convolution's descriptor (ksize 3, stride 2, even hin/win; cout_pad =
+ * channels of dz's planes); dx has cin_pad (multiple of 32) channel planes of hin x win; residual (may alias dx) is
+ * added before the bf16 rounding; ones / zeros: cin_pad floats of 1 / 0 (the kernel's affine epilogue).
+ * Filters from ay_pack_dgrad_s2_weights_bf16: [class py*2+px][cout_pad/16][window tap][2][cin_pad][8] bf16. */
+size_t ay_packed_dgrad_s2_weight_bytes(int cout_pad, int cin_pad);
+int ay_pack_dgrad_s2_weights_bf16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int cin_pad, ay_stream_t stream);
+int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, const void* w_s2_packed, const float* ones, const float* zeros,
+                          const void* residual, void* dx, int cin_pad, ay_stream_t stream);
 /* weight gradient on the MFMA path: dW (OIHW fp32, overwritten) from blocked bf16 input x and output gradient dz
  * (desc as in the forward; cout_pad = channels of dz's planes) */
 int ay_conv_wgrad_bf16(const ay_conv_desc* d, const void* x_blocked, const void* dz_blocked, float* dw_oihw, ay_stream_t stream);

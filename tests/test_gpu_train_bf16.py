@@ -119,6 +119,52 @@ def test_dgrad_through_forward_kernel(case):
     assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-3).all()), float(err.max())
 
 
+S2_DGRAD_CASES = [(32, 64, 72, True), (64, 128, 40, True), (128, 256, 36, False), (256, 512, 20, True), (512, 1024, 16, True), (16, 48, 24, False), (48, 80, 24, True)]
+
+
+@pytest.mark.parametrize("case", S2_DGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_dgrad_s2_parity_classes(case):
+    """ay_conv_dgrad_s2_bf16 (four 2x2-window sub-convolutions of dz, no zero insertion) against autograd through
+    F.conv2d(stride=2) on the bf16-rounded filters (what loss.backward() does in the reference, train.py:113 /
+    models.py:33-41), with and without a gradient already accumulated in dx; ragged tiles (sizes off the 8x32 tile), every
+    channel tile (32 / 64 / 128 output channels of the kernel) and a padded channel count."""
+    cin, cout, H, has_prev = case
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = _lib.stream_ptr()
+    B = 2
+    g = torch.Generator().manual_seed(cin * 5 + cout + H)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cout * 9 / 4)
+    x = torch.zeros(B, cin, H, H, requires_grad=True)
+    y = F.conv2d(x, bf(w), None, 2, 1)
+    dz = bf(torch.randn(y.shape, generator=g))
+    y.backward(dz)
+    Ho = y.shape[2]
+    assert H == 2 * Ho
+    prev = bf(torch.randn(B, cin, H, H, generator=g))
+    ref = bf(x.grad + prev) if has_prev else bf(x.grad)
+    cpad = (cout + 31) // 32 * 32
+    cin_pad = (cin + 31) // 32 * 32
+    def padded(t, c):   # the converter lays images out by ceil16(channels) planes: pad the channel axis on the host
+        out = torch.zeros(t.shape[0], c, t.shape[2], t.shape[3])
+        out[:, : t.shape[1]] = t
+        return out
+
+    dzb = to_blocked(padded(dz, cpad), dev)
+    packed = torch.empty(L.ay_packed_dgrad_s2_weight_bytes(cpad, cin_pad), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_dgrad_s2_weights_bf16(ptr(w.to(dev)), ptr(packed), cout, cpad, cin, cin_pad, st))
+    ones, zeros = torch.ones(cin_pad, device=dev), torch.zeros(cin_pad, device=dev)
+    dx = to_blocked(padded(prev, cin_pad), dev) if has_prev else torch.full((B, cin_pad // 16, H, H, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    d = ConvDesc(B, cin, cout, H, H, Ho, Ho, 3, 2, 0, 0, cpad)
+    check(L.ay_conv_dgrad_s2_bf16(C.byref(d), ptr(dzb), ptr(packed), ptr(ones), ptr(zeros), ptr(dx) if has_prev else None, ptr(dx), cin_pad, st), "dgrad s2")
+    full = from_blocked(dx, cin_pad)
+    assert bool(torch.isfinite(full).all())
+    got = full[:, :cin]
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-3).all()), float(err.max())
+    assert cin_pad == cin or float(full[:, cin:].abs().max()) == 0.0   # planes beyond cin: zero filters, zero accumulated gradient
+
+
 def test_bn_train_bf16_fwd_bwd_and_plumbing():
     L = _lib.lib()
     dev = torch.device("cuda", 0)
