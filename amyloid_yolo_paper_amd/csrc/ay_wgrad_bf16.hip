@@ -13,6 +13,8 @@
 // a 32-lane half reads land on different banks.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ay_common.h"
 
 namespace ay {
@@ -25,6 +27,8 @@ struct WgradArgs {
     float* dw;
     int B, cin, cout, CIP, COP, hin, win, ho, wo;
     int nseg_x, total_segs;
+    int ncob, ncib, ks;      // workgroup grid: ncob x ncib filter tiles x ks split-K slices, flattened into blockIdx.x (see the kernel)
+    unsigned m_nseg, m_ho;   // floor(2^32 / nseg_x), floor(2^32 / ho) (0xffffffff for a divisor of 1): multiply-high division in the K loop
     float* slab;       // split-K partial filters [gridDim.z][dw_elems] (plain stores, summed in fixed order by wgrad_reduce_kernel);
     size_t dw_elems;   // nullptr: the partial sums are added to dw with fp32 atomics
 };
@@ -34,11 +38,17 @@ __device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2);
 // SEGS: row segments per K step (and per barrier).  1x1 layers have 4 MFMAs per wave and segment: one segment per step left the
 // kernel barrier-bound (173 us per launch on average at B=32 / 1024^2 against ~70 us of HBM time); they take 4 segments per step
 // from a ring of 3 stages.
-template <int KS, int STRIDE, int SEGS = 1, int NBUF = 4>
-__global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
+// CO_PL x CI_PL: channel planes (of 16) of dz / x per workgroup.  8 x 4 (128 x 64 filters, 4 co planes per wave) for the body of
+// the network; the narrow layers at its ends -- 32 x 3, 64 x 32, 32 x 64 filters over the LARGEST images -- use 4 x 2 (3x3) or 2 x 4
+// (1x1) with one plane pair per wave: their launches are bound by memory latency, not by anything a wave does (2048 K steps of
+// ~1.4 us with one or two waves multiplying), and the small tile's ring is half the size, so two workgroups share a CU and twice
+// the segments are in flight.
+template <int KS, int STRIDE, int SEGS = 1, int NBUF = 4, int CO_PL = 8, int CI_PL = 4>
+__global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
-    constexpr int CO_PL = 8, CI_PL = 4, COW = 4;       // planes per workgroup; co planes per wave
+    constexpr int COW = CO_PL * CI_PL / 8;              // co planes per wave: 8 waves = (CO_PL / COW) x CI_PL
+    static_assert(COW >= 1 && (CO_PL / COW) * CI_PL == 8 && CO_PL % COW == 0, "8 waves");
     constexpr int XW = 31 * STRIDE + KS;                // input pixels per row of a segment
     constexpr int DZ_UNITS = CO_PL * 32 * 2;            // 16-byte units
     constexpr int X_UNITS = CI_PL * KS * XW * 2;
@@ -50,24 +60,42 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int BUF_BYTES = NPIECE * 1024;            // one segment
     constexpr int DUMMY = NBUF * SEGS * BUF_BYTES;
     constexpr int PWS = PW * SEGS;                      // DMA pieces per wave and stage
-    static_assert(NBUF * SEGS * BUF_BYTES + 1024 <= 160 * 1024, "LDS");
-    static_assert(8 * 16 * 16 * KK2 * 4 <= NBUF * SEGS * BUF_BYTES, "epilogue staging reuses the stage buffers");
+    constexpr int RING_BYTES = NBUF * SEGS * BUF_BYTES;
+    constexpr int STAGING_BYTES = 8 * 16 * 16 * KK2 * 4;   // the epilogue's transposes reuse the stage buffers
+    constexpr int LDS_BYTES = (RING_BYTES > STAGING_BYTES ? RING_BYTES : STAGING_BYTES) + 1024;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(NBUF == 3 || NBUF == 4, "ring depth");
 
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF * SEGS * BUF_BYTES + 1024];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave / CI_PL, iw = wave % CI_PL;
-    const int cob = blockIdx.x, cib = blockIdx.y;
+    // Workgroup -> (filter tile, split-K slice).  The ncob x ncib tiles of one slice read the same pixels -- x is shared by the ncob
+    // tiles of a ci block, dz by the ncib tiles of a co block -- and the slices sweep the image in step, so the tiles of a slice
+    // belong on ONE XCD (one L2) at the same time: workgroups go to XCDs round-robin by their linear id, so id = 8 * idx + xcd
+    // takes tile idx % ntiles of slice (idx / ntiles) * 8 + xcd (ks is a multiple of 8 then).  With the plain (x, y, z) grid the four
+    // tiles of a slice sat on four XCDs and every byte was fetched from HBM / Infinity Cache once per tile: 4.3 TB/s of traffic at
+    // 0.38 of the matrix peak.
+    const int ntiles = a.ncob * a.ncib;
+    int tile, zslice;
+    if ((a.ks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = idx % ntiles;
+        zslice = (idx / ntiles) * 8 + xcd;
+    } else {
+        tile = blockIdx.x % ntiles;
+        zslice = blockIdx.x / ntiles;
+    }
+    const int cob = tile % a.ncob, cib = tile / a.ncob;
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const unsigned lds_base = lds_addr_of(lds);
 
     // segment groups (SEGS consecutive segments) of this workgroup: blockIdx.z, + gridDim.z, ...
-    const int seg = blockIdx.z;
+    const int seg = zslice;
     const int total_groups = (a.total_segs + SEGS - 1) / SEGS;
-    const int nstep = (total_groups - seg + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int nstep = (total_groups - seg + a.ks - 1) / a.ks;
     if (nstep <= 0) return;
 
     // ---- loader.  Which unit of a tile a lane carries in piece i (plane, row / tap row, pixel slot, channel half) does not depend
@@ -106,34 +134,47 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
             }
         }
     }
-    auto issue = [&](int sg, int buf) __attribute__((always_inline)) {
-        const bool seg_ok = sg < a.total_segs;  // the tail of the last group: every lane out of range, the buffer reads as zeros
-        if (!seg_ok) sg = 0;
-        const int xs = sg % a.nseg_x;
-        const int oy = (sg / a.nseg_x) % a.ho;
-        const int b = sg / (a.nseg_x * a.ho);
-        const int ox0 = xs * 32;
-        const long long org_dz = ((long long)oy * a.wo + ox0) * 32;
-        const long long org_x = ((long long)(oy * STRIDE - PAD) * a.win + (ox0 * STRIDE - PAD)) * 32;   // negative in the first row
-        const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dz) + (long long)b * a.COP * dz_plane + org_dz, 0,
-                                                                          0x7ffffffc, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.x) + (long long)b * a.CIP * x_plane + org_x, 0,
-                                                                         0x7ffffffc, 0x00020000);
-        const unsigned so_dz = 0u, so_x = 0u;
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int qn = i * 8 + wave;  // wave-uniform piece id
-            if (qn < DZ_PIECES) {
-                const unsigned vo = (seg_ok && ox0 + lane_dx[i] < a.wo) ? lane_off[i] : OOB;
-                dma16_buf(rdz, vo, so_dz, lds_base + buf * BUF_BYTES + qn * 1024);
-            } else if (qn < NPIECE) {
-                const int iy = oy * STRIDE + lane_dy[i], ix = ox0 * STRIDE + lane_dx[i];
-                const unsigned vo = (seg_ok && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) ? lane_off[i] : OOB;
-                dma16_buf(rx, vo, so_x, lds_base + buf * BUF_BYTES + qn * 1024);
-            } else {
-                dma16_buf(rx, OOB, 0u, lds_base + DUMMY);   // keeps the per-wave piece count constant (counted vmcnt waits)
-            }
+    // Source of one segment: wave-uniform.  The coordinates come from two multiply-high divisions (the compiler's expansion of
+    // three run-time divisions and two remainders per segment was ~300 scalar instructions per stage and wave, issued in front of
+    // the stage's MFMAs: SQ_ACTIVE_INST_SCA 0.20 of the wave cycles, matrix pipe 42 % busy).
+    struct SegSrc {
+        __amdgpu_buffer_rsrc_t rdz, rx;
+        int oy, ox0;
+        bool ok;
+    };
+    auto seg_src = [&](int sg) __attribute__((always_inline)) {
+        SegSrc S;
+        S.ok = sg < a.total_segs;  // the tail of the last group: every lane out of range, the buffer reads as zeros
+        if (!S.ok) sg = 0;
+        unsigned row = __umulhi((unsigned)sg, a.m_nseg), xs = (unsigned)sg - row * (unsigned)a.nseg_x;   // row = b * ho + oy
+        if (xs >= (unsigned)a.nseg_x) ++row, xs -= (unsigned)a.nseg_x;
+        unsigned b = __umulhi(row, a.m_ho), oy = row - b * (unsigned)a.ho;
+        if (oy >= (unsigned)a.ho) ++b, oy -= (unsigned)a.ho;
+        S.oy = (int)oy;
+        S.ox0 = (int)xs * 32;
+        const long long org_dz = ((long long)S.oy * a.wo + S.ox0) * 32;
+        const long long org_x = ((long long)(S.oy * STRIDE - PAD) * a.win + (S.ox0 * STRIDE - PAD)) * 32;   // negative in the first row
+        S.rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dz) + (long long)b * a.COP * dz_plane + org_dz, 0, 0x7ffffffc, 0x00020000);
+        S.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.x) + (long long)b * a.CIP * x_plane + org_x, 0, 0x7ffffffc, 0x00020000);
+        return S;
+    };
+    auto issue_piece = [&](const SegSrc& S, int i, int buf) __attribute__((always_inline)) {   // piece i (of PW) of this wave
+        const int qn = i * 8 + wave;  // wave-uniform piece id
+        if (qn < DZ_PIECES) {
+            const unsigned vo = (S.ok && S.ox0 + lane_dx[i] < a.wo) ? lane_off[i] : OOB;
+            dma16_buf(S.rdz, vo, 0u, lds_base + buf * BUF_BYTES + qn * 1024);
+        } else if (qn < NPIECE) {
+            const int iy = S.oy * STRIDE + lane_dy[i], ix = S.ox0 * STRIDE + lane_dx[i];
+            const unsigned vo = (S.ok && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) ? lane_off[i] : OOB;
+            dma16_buf(S.rx, vo, 0u, lds_base + buf * BUF_BYTES + qn * 1024);
+        } else {
+            dma16_buf(S.rx, OOB, 0u, lds_base + DUMMY);   // keeps the per-wave piece count constant (counted vmcnt waits)
         }
+    };
+    auto issue = [&](int sg, int buf) __attribute__((always_inline)) {
+        const SegSrc S = seg_src(sg);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) issue_piece(S, i, buf);
     };
 
     // fragment addresses (buffer-relative)
@@ -152,8 +193,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int t = 0; t < KK2; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // co planes of this wave that exist (0: the wave has nothing to multiply)
+    const int wave_nj = (cib * CI_PL + iw < a.CIP) ? min(max(a.COP - (cob * CO_PL + cw * COW), 0), COW) : 0;
+
     auto issue_stage = [&](int step, int slot) __attribute__((always_inline)) {
-        const int group = seg + step * (int)gridDim.z;
+        const int group = seg + step * a.ks;
 #pragma unroll
         for (int j = 0; j < SEGS; ++j) issue(group * SEGS + j, slot * SEGS + j);
     };
@@ -173,35 +217,68 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     asm volatile("" ::: "memory");
 
     int cur = 0, nxt = (NBUF - 1) % NBUF;
+    constexpr int NGROUP = SEGS * KK2;   // MFMA groups (one tap of one segment: COW MFMAs) per stage; the stage's PWS pieces are spread over them
     for (int k = 0; k < nstep; ++k) {
-        if (issued < nstep) {
-            issue_stage(issued, nxt);
-            ++issued;
+        // stage `issued` goes into the slot read in the previous iteration; its DMA pieces are issued one by one BEHIND the MFMA
+        // groups of this stage (a piece costs the wave its address selects + the DMA issue; in a burst in front of the MFMAs both
+        // waves of a SIMD pay that with the matrix pipe idle)
+        const bool do_issue = issued < nstep;
+        SegSrc nsrc[SEGS];
+        if (do_issue) {
+            const int group = seg + issued * a.ks;
+#pragma unroll
+            for (int j = 0; j < SEGS; ++j) nsrc[j] = seg_src(group * SEGS + j);
         }
+        const int slot_ld = nxt;
         if (++nxt == NBUF) nxt = 0;
+        // (explicit software pipelining of the fragment reads -- x fragments two tap groups ahead, dz fragments of the next segment in a
+        // second buffer -- was measured: +1 % at 18 more VGPRs, which spill once the narrow-layer paths below exist; left to the compiler)
+        auto read_frag = [&](const uint8_t* p0, const uint8_t* p1) __attribute__((always_inline)) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+            const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16x8 f;
+            __builtin_memcpy(&f, v, 16);
+            return f;
+        };
+        const uint8_t* Lst = lds + cur * SEGS * BUF_BYTES;
+        auto read_b = [&](int u) __attribute__((always_inline)) {   // tap group u of the stage = (segment u / KK2, tap u % KK2)
+            const int sj = u / KK2, t = u % KK2, kh = t / KS, kw = t % KS;
+            return read_frag(Lst + sj * BUF_BYTES + boff[kw][0] + kh * XW * 32, Lst + sj * BUF_BYTES + boff[kw][1] + kh * XW * 32);
+        };
+        // NJ: co planes this wave really has (COW, 2, or 0 = none: its ci plane or all its co planes lie beyond the tensor, it only
+        // takes part in the DMA and the barriers).  Narrow layers leave most of the 128 x 64 tile empty -- the stem (32 x 3 filters)
+        // has ONE wave with two planes -- and MFMAs on zero planes were all of their time (stem 4.1 ms, 32->64 1.1 ms per step).
+        auto stage_body = [&](auto njc) __attribute__((always_inline)) {
+            constexpr int NJ = decltype(njc)::value;
 #pragma unroll
-        for (int sj = 0; sj < SEGS; ++sj) {
-            const uint8_t* L = lds + (cur * SEGS + sj) * BUF_BYTES;
-            bf16x8 af[COW];
+            for (int sj = 0; sj < SEGS; ++sj) {
+                bf16x8 af[COW];
 #pragma unroll
-            for (int j = 0; j < COW; ++j) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[0] + j * 1024));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + aoff[1] + j * 1024));
-                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                __builtin_memcpy(&af[j], v, 16);
+                for (int j = 0; j < NJ; ++j) af[j] = read_frag(Lst + sj * BUF_BYTES + aoff[0] + j * 1024, Lst + sj * BUF_BYTES + aoff[1] + j * 1024);
+#pragma unroll
+                for (int t = 0; t < KK2; ++t) {
+                    const int u = sj * KK2 + t;
+                    if constexpr (NJ > 0) {
+                        const bf16x8 bfr = read_b(u);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[j][t], 0, 0, 0);
+                    }
+                    if (do_issue) {
+#pragma unroll
+                        for (int n = 0; n < PWS; ++n)   // constant trip count: lane_off[] must stay in registers
+                            if (n >= u * PWS / NGROUP && n < (u + 1) * PWS / NGROUP) issue_piece(nsrc[n / PW], n % PW, slot_ld * SEGS + n / PW);
+                    }
+                }
             }
-#pragma unroll
-            for (int t = 0; t < KK2; ++t) {
-                const int kh = t / KS, kw = t % KS;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][0] + kh * XW * 32));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(L + boff[kw][1] + kh * XW * 32));
-                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bf16x8 bfr;
-                __builtin_memcpy(&bfr, v, 16);
-#pragma unroll
-                for (int j = 0; j < COW; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[j][t], 0, 0, 0);
-            }
-        }
+        };
+        if (wave_nj > 2)
+            stage_body(std::integral_constant<int, COW>{});
+        else if (wave_nj > 0)
+            stage_body(std::integral_constant<int, (COW < 2 ? COW : 2)>{});
+        else
+            stage_body(std::integral_constant<int, 0>{});
+        if (do_issue) ++issued;
         if (k + 1 < nstep) {
             wait_landed(issued - (k + 1) - 1);  // stages issued beyond k+1 may stay in flight
             __builtin_amdgcn_s_barrier();
@@ -223,6 +300,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int ROW = 16 * KK2;  // floats per co row of one ci plane
 #pragma unroll
     for (int j = 0; j < COW; ++j) {
+        if (j >= wave_nj) break;   // planes beyond the tensor: nothing to store
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -236,7 +314,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_bf16_kernel(WgradArgs a) {
             if (co < a.cout && ci < a.cin) {
                 const size_t off = ((size_t)co * a.cin + ci0) * KK2 + rem;
                 if (a.slab)
-                    a.slab[(size_t)blockIdx.z * a.dw_elems + off] = stage[idx];
+                    a.slab[(size_t)zslice * a.dw_elems + off] = stage[idx];
                 else
                     atomicAdd(a.dw + off, stage[idx]);
             }
@@ -272,19 +350,30 @@ constexpr int WGRAD_SEGS_1X1 = 4;
 #endif
 constexpr int WGRAD_SEGS_3X3 = AY_WGRAD_SEGS_3X3;   // 3x3 stride 1: 2 segments per K step from a ring of 3 stages (126 KiB)
 
+// narrow layers (see the kernel template): 3x3 with at most 4 x 2 planes, 1x1 with at most 2 x 4
+static bool wgrad_narrow(const ay_conv_desc* d) {
+    static const int on = getenv("AY_WGRAD_NARROW") ? atoi(getenv("AY_WGRAD_NARROW")) : 1;
+    const int CIP = (d->cin + 15) / 16;
+    const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
+    return on && (d->ksize == 3 ? (COP <= 4 && CIP <= 2) : (COP <= 2 && CIP <= 4));
+}
+
 static long long wgrad_split(const ay_conv_desc* d, int* cob, int* cib, long long* total) {
     const int CIP = (d->cin + 15) / 16;
     const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
     *cob = (COP + 7) / 8;
     *cib = (CIP + 3) / 4;
+    const bool narrow = wgrad_narrow(d);
+    if (narrow) *cob = *cib = 1;
     *total = (long long)d->batch * d->hout * ((d->wout + 31) / 32);
     if (d->ksize == 1) *total = (*total + WGRAD_SEGS_1X1 - 1) / WGRAD_SEGS_1X1;   // K steps = groups of segments
     if (d->ksize == 3 && d->stride == 1) *total = (*total + WGRAD_SEGS_3X3 - 1) / WGRAD_SEGS_3X3;
     static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
-    long long ks = (wg_target + (long long)*cob * *cib - 1) / ((long long)*cob * *cib);   // ~1 workgroup per CU overall ...
+    long long ks = ((narrow ? 2 : 1) * wg_target + (long long)*cob * *cib - 1) / ((long long)*cob * *cib);   // ~1 workgroup per CU overall (narrow: 2) ...
     if (ks > *total / 24) ks = *total / 24;                                            // ... but >= 24 K steps each (pipeline fill, epilogue)
     if (ks > *total) ks = *total;
     if (ks > 65535) ks = 65535;
+    if (ks >= 8) ks -= ks % 8;   // whole slices per XCD (see the kernel's workgroup mapping)
     if (ks < 1) ks = 1;
     return ks;
 }
@@ -329,6 +418,9 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
     a.ho = d->hout;
     a.wo = d->wout;
     a.nseg_x = (d->wout + 31) / 32;
+    auto magic = [](unsigned dv) { return dv <= 1 ? 0xffffffffu : (unsigned)(0x100000000ULL / dv); };
+    a.m_nseg = magic((unsigned)a.nseg_x);
+    a.m_ho = magic((unsigned)d->hout);
     const long long total = (long long)d->batch * d->hout * a.nseg_x;
     AY_CHECK_ARG(total > 0 && total < 0x7fffffffLL, "ay_conv_wgrad_bf16: too many segments");
     a.total_segs = (int)total;
@@ -344,8 +436,17 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
         set_error("ay_conv_wgrad_bf16: memset failed");
         return AY_ERR_LAUNCH;
     }
-    dim3 grid(cob, cib, (unsigned)ks), block(512);
-    if (d->ksize == 3 && d->stride == 1)
+    a.ncob = cob, a.ncib = cib, a.ks = (int)ks;
+    AY_CHECK_ARG((long long)cob * cib * ks < 0x7fffffffLL, "ay_conv_wgrad_bf16: grid");
+    dim3 grid((unsigned)(cob * cib * ks)), block(512);
+    if (wgrad_narrow(d)) {
+        if (d->ksize == 3 && d->stride == 1)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_SEGS_3X3 == 1 ? 4 : 3, 4, 2>), grid, block, 0, st, a);
+        else if (d->ksize == 3)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2, 1, 4, 4, 2>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1, 3, 2, 4>), grid, block, 0, st, a);
+    } else if (d->ksize == 3 && d->stride == 1)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_SEGS_3X3 == 1 ? 4 : 3>), grid, block, 0, st, a);
     else if (d->ksize == 3)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2>), grid, block, 0, st, a);

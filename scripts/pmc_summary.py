@@ -18,7 +18,7 @@ for k in agg:  # a counter collected in several passes: mean over the passes
         agg[k][c] /= len(passes[k][c])
 names = sorted({c for v in agg.values() for c in v})
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0)):
-    if "conv" not in k and "resblock" not in k and "stem" not in k:
+    if not any(t in k for t in ("conv", "resblock", "stem", "wgrad", "bn_")):
         continue
     print(f"{k}  (n={calls[k]})")
     base = v.get("SQ_WAVE_CYCLES") or v.get("SQ_BUSY_CYCLES") or 1.0

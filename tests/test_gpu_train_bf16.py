@@ -37,7 +37,7 @@ def from_blocked(tb, Cc):
 
 
 WGRAD_CASES = [(3, 32, 3, 1, 40, 2), (32, 64, 3, 1, 40, 2), (64, 128, 3, 1, 32, 3), (128, 256, 3, 2, 26, 2), (256, 128, 1, 1, 26, 2),
-               (32, 64, 3, 2, 64, 2), (1024, 24, 1, 1, 13, 2), (16, 48, 3, 1, 9, 1), (512, 1024, 3, 1, 8, 2)]
+               (32, 64, 3, 2, 64, 2), (1024, 24, 1, 1, 13, 2), (16, 48, 3, 1, 9, 1), (512, 1024, 3, 1, 8, 2), (64, 32, 1, 1, 40, 2)]
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
