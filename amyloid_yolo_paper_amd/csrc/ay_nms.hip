@@ -61,7 +61,9 @@ __global__ void nms_filter_kernel(float* __restrict__ pred, int N, int C, float 
             const float score = conf * mc;
             const unsigned sb = __builtin_bit_cast(unsigned, score);
             const int pos = atomicAdd(&cand_count[b], 1);
-            kb[pos] = ((unsigned long long)(~sb) << 32) | (unsigned)r;
+            // (a candidate count that does not start at zero -- a zero-fill lost or reordered upstream -- must not turn into a
+            // write past this image's keys)
+            if ((unsigned)pos < (unsigned)cap) kb[pos] = ((unsigned long long)(~sb) << 32) | (unsigned)r;
         }
     }
 }
