@@ -101,7 +101,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
     constexpr int D = 3;  // fetch-ahead distance in items
     auto fetch_id = [&](int prev) __attribute__((always_inline)) -> int {  // thread 0 only
         if (prev >= last) return last;
-        return dyn ? first + D * slots + (int)atomicAdd(a.deal + xcd, 1u) : prev + slots;
+        if (!dyn) return prev + slots;
+        // whatever the counter holds, the id stays inside this XCD's range or reads as "no more items"
+        const unsigned n = atomicAdd(a.deal + xcd, 1u);
+        return n < (unsigned)(last - first) ? first + D * slots + (int)n : last;
     };
     if (tid < D) mbox[tid] = min(item + tid * slots, last);
     __syncthreads();

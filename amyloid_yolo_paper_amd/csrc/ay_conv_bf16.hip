@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     const int D = (a.cin / (16 * NK)) >= 2 ? 3 : 5;  // fetch-ahead distance in items
     auto fetch_id = [&](int prev) __attribute__((always_inline)) -> int {  // thread 0 only
         if (prev >= last) return last;
-        return dyn ? first + D * slots + (int)atomicAdd(a.deal + xcd, 1u) : prev + slots;
+        if (!dyn) return prev + slots;
+        // whatever the counter holds, the id stays inside this XCD's range or reads as "no more items"
+        const unsigned n = atomicAdd(a.deal + xcd, 1u);
+        return n < (unsigned)(last - first) ? first + D * slots + (int)n : last;
     };
     if (MAILBOX && tid < D) mbox[tid] = min(item + tid * slots, last);  // the first D items of a workgroup are static (no atomics, no
                                                              // wait in the prologue); id[c+D] is posted by the epilogue of item c
