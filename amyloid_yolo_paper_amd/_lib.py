@@ -92,6 +92,9 @@ _SIGS = {
     "ay_slice_accumulate_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ay_zero_insert_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ay_pack_dgrad_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_stem_train_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ay_stem_train_wgrad_workspace_bytes": (C.c_size_t, []),
+    "ay_stem_train_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _I, _I, _I, _P]),
     "ay_packed_dgrad_s2_weight_bytes": (C.c_size_t, [_I, _I]),
     "ay_pack_dgrad_s2_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_conv_dgrad_s2_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P]),

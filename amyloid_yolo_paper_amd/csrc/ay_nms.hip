@@ -47,6 +47,25 @@ __global__ void nms_filter_kernel(float* __restrict__ pred, int N, int C, float 
     const int K = 5 + C;
     float* pb = pred + (size_t)b * N * K;
     unsigned long long* kb = keys + (size_t)b * cap;
+    if (K == 8 && (reinterpret_cast<uintptr_t>(pred) & 15) == 0) {
+        // 3 classes (the paper's model): a row is 32 aligned bytes -- two 16-byte loads and one 16-byte store per row instead of
+        // eight scalar loads and four scalar stores (this kernel runs beside the next batch's convolutions: the fewer memory
+        // instructions it issues the less it takes from them).  Same operations on the same values.
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
+            float4* p4 = reinterpret_cast<float4*>(pb + (size_t)r * 8);
+            const float4 bx = p4[0], cf = p4[1];
+            const float hw = bx.z / 2.0f, hh = bx.w / 2.0f;
+            p4[0] = make_float4(bx.x - hw, bx.y - hh, bx.x + hw, bx.y + hh);
+            if (cf.x >= conf_thres) {
+                const float mc = fmaxf(fmaxf(cf.y, cf.z), cf.w);
+                const float score = cf.x * mc;
+                const unsigned sb = __builtin_bit_cast(unsigned, score);
+                const int pos = atomicAdd(&cand_count[b], 1);
+                if ((unsigned)pos < (unsigned)cap) kb[pos] = ((unsigned long long)(~sb) << 32) | (unsigned)r;
+            }
+        }
+        return;
+    }
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
         float* p = pb + (size_t)r * K;
         const float cx = p[0], cy = p[1], hw = p[2] / 2.0f, hh = p[3] / 2.0f;

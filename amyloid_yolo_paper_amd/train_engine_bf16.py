@@ -28,6 +28,8 @@ from .train_engine import METRIC_KEYS, _ws
 
 # AY_S2_DGRAD=0: data gradient of the stride-2 layers as a stride-1 convolution over the zero-inserted output gradient (round 1)
 _S2_DGRAD = os.environ.get("AY_S2_DGRAD", "1") != "0"
+# AY_STEM_DIRECT=0: the stem through the generic kernels on a zero-padded 16-channel bf16 copy of the image (round 1)
+_STEM_DIRECT = os.environ.get("AY_STEM_DIRECT", "1") != "0"
 
 
 def _pad(v, m):
@@ -148,6 +150,13 @@ def _pack_weights(model, ctx):
         w = conv.weight.detach()
         rec = ctx.packed.setdefault(i, {})
         cin_eff = cin
+        if e["src"] < 0 and _STEM_DIRECT and cout == 32 and cin == 3 and k == 3 and e["stride"] == 1:
+            # stem straight from the fp32 image (ay_stem_train_*): bf16 filters [32][32], index ci*9 + kh*3 + kw
+            w0f = ctx.get(("w0f", i), (32, 32), torch.float32, zero=True)
+            w0f[:, :27].copy_(w.reshape(32, 27))
+            w0 = ctx.get(("w0", i), (32, 32), torch.bfloat16)
+            w0.copy_(w0f)
+            rec.update(stem_w0=w0)
         if e["src"] < 0:  # stem: filters get zero input channels 3..15
             w16 = ctx.get(("w16", i), (cout, 16, k, k), torch.float32, zero=True)
             w16[:, :cin].copy_(w)
@@ -229,7 +238,10 @@ def train_forward_bf16(model, x, targets):
             cout, cin, k = e["cout"], e["cin"], e["k"]
             pk = packed[i]
             cpad, cin_eff = pk["cpad"], pk["cin_eff"]
-            if e["src"] < 0:
+            stem_direct = e["src"] < 0 and "stem_w0" in pk and hin % 4 == 0
+            if stem_direct:
+                src = x   # ---- stem straight from the fp32 image: forward and filter gradient read it once (ay_stem_train.hip)
+            elif e["src"] < 0:
                 # ---- stem: the fp32 image becomes ONE zero-padded 16-channel bf16 plane and the layer runs through the
                 # same MFMA kernels as every other layer
                 assert e["bn"] and cin <= 16
@@ -240,7 +252,7 @@ def train_forward_bf16(model, x, targets):
             is_head = not e["bn"]
             ones, zeros = model._unit(cpad, dev)
             d = ConvDesc(B, cin_eff, cout, hin, hin, hout, hout, k, e["stride"], 0, int(is_head), cpad)
-            rec = dict(kind="head" if is_head else "bn", x=src, desc=d, src=e["src"], cpad=cpad, stem=e["src"] < 0)
+            rec = dict(kind="head" if is_head else "bn", x=src, desc=d, src=e["src"], cpad=cpad, stem=e["src"] < 0, stem_direct=stem_direct)
             if is_head:
                 shift = ctx.get(("shift", i), (cpad,), torch.float32, zero=True)
                 shift[:cout].copy_(conv.bias.detach())
@@ -254,8 +266,11 @@ def train_forward_bf16(model, x, targets):
             bn = m[1]
             assert cout % 32 == 0, f"layer {i}: the bf16 training path needs BN layers with a multiple of 32 filters (got {cout})"
             z = blocked(("z", i), cout, hout, pad=32)
-            with _Timed(prof, "conv", _family(e)):
-                check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
+            if stem_direct:
+                check(L.ay_stem_train_fwd_bf16(ptr(x), ptr(pk["stem_w0"]), ptr(z), B, hin, hin, st), "ay_stem_train_fwd_bf16")
+            else:
+                with _Timed(prof, "conv", _family(e)):
+                    check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
             fuse = e["fuse_into_shortcut"]
             skip = resolve(graph[i + 1]["b"]) if fuse else None
             y = blocked(("y", i), cout, hout, pad=32)
@@ -453,6 +468,17 @@ def train_backward_bf16(model, stt, grad_scale=None):
         if keep_dz is not None and i in keep_dz:
             keep_dz[i] = dz.clone()
         # ---- weight gradient (matrix cores, K = pixels), added into conv.weight.grad
+        if rec.get("stem_direct"):
+            nws = L.ay_stem_train_wgrad_workspace_bytes()
+            wws = ctx.buf.get("wgrad_ws")
+            if wws is None or wws.numel() < nws:
+                wws = ctx.buf["wgrad_ws"] = torch.empty(max(nws, 1 << 20), device=dev, dtype=torch.uint8)
+            check(L.ay_stem_train_wgrad_bf16(ptr(rec["x"]), ptr(dz), ptr(conv.weight.grad), 1, ptr(wws), wws.numel(), B, hin, hin, st),
+                  "ay_stem_train_wgrad_bf16")
+            if hook is not None:
+                hook(i)
+            pool.put(dz)
+            continue
         if rec.get("stem"):
             d_w = ConvDesc(B, cin, cout, hin, hin, hout, hout, k, e["stride"], 0, 0, rec["cpad"])  # cin = 3: rows ci >= 3 of the plane are skipped
         else:

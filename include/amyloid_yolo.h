@@ -266,6 +266,16 @@ int ay_zero_insert_bf16(const void* in, void* out, int batch, int channels, int 
 /* filters that make ay_conv_fwd_bf16 compute the data gradient: W'[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw], packed
  * [ceil(cout/16)][k*k][2][cin_pad][8]; use with desc{cin=ceil16(cout), cout=cin, cout_pad=cin_pad, stride 1}. */
 int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int cin, int cin_pad, int ksize, ay_stream_t stream);
+/* The stem Conv2d(3, 32, 3, 1, 1) (models.py:33-41, layer 0) on the bf16 training path, straight from the fp32 NCHW image (W % 4 == 0,
+ * 16-byte aligned): forward z = bf16(conv(bf16(x), bf16(w))) with fp32 accumulation -> blocked bf16 [B][2][H][W][16]
+ * (w_bf16: [32][32] bf16, index ci*9 + kh*3 + kw, entries 27..31 unused), and the filter gradient dW[32][3][3][3] (fp32,
+ * overwritten or, accumulate != 0, added to) from the blocked bf16 output gradient; partial sums per workgroup go to
+ * `workspace` (ay_stem_train_wgrad_workspace_bytes()) and are added in a fixed order.  What loss.backward() (train.py:113)
+ * computes for that layer, on bf16-rounded operands. */
+int ay_stem_train_fwd_bf16(const float* x_nchw, const void* w_bf16, void* z_blocked, int batch, int h, int w, ay_stream_t stream);
+size_t ay_stem_train_wgrad_workspace_bytes(void);
+int ay_stem_train_wgrad_bf16(const float* x_nchw, const void* dz_blocked, float* dw_oihw, int accumulate, void* workspace,
+                             size_t workspace_bytes, int batch, int h, int w, ay_stream_t stream);
 /* Data gradient of a 3x3 stride-2 convolution (the reference gets it from autograd: loss.backward(), train.py:113, through
  * nn.Conv2d(stride=2), models.py:33-41) WITHOUT zero insertion: output pixel (y, x) only receives the filter taps with
  * (y + 1 - kh) and (x + 1 - kw) even, so each parity class (y & 1, x & 1) of dx is a stride-1 convolution of dz with a

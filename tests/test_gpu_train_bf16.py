@@ -119,6 +119,47 @@ def test_dgrad_through_forward_kernel(case):
     assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-3).all()), float(err.max())
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 64, 64), (3, 24, 132)], ids=str)
+def test_stem_train_kernels(shape):
+    """ay_stem_train_fwd_bf16 / ay_stem_train_wgrad_bf16 (layer 0 on the bf16 training path straight from the fp32 image) against
+    F.conv2d on the bf16-rounded image and filters and its autograd filter gradient (what loss.backward() computes for
+    models.py:33-41's first Conv2d, train.py:113); ragged tiles (sizes off the 8x64 item), accumulate on and off."""
+    B, H, W = shape
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.rand(B, 3, H, W, generator=g)
+    w = (torch.randn(32, 3, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    wb = bf(w.detach()).requires_grad_(True)
+    y = F.conv2d(bf(x), wb, None, 1, 1)
+    dz = bf(torch.randn(y.shape, generator=g))
+    y.backward(dz)
+    ref_z, ref_dw = bf(y.detach()), wb.grad
+    w0 = torch.zeros(32, 32)
+    w0[:, :27] = w.detach().reshape(32, 27)
+    xd, w0d = x.to(dev), w0.to(torch.bfloat16).to(dev)
+    zb = torch.full((B, 2, H, W, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(L.ay_stem_train_fwd_bf16(ptr(xd), ptr(w0d), ptr(zb), B, H, W, st), "stem fwd")
+    got = from_blocked(zb, 32)
+    assert bool(torch.isfinite(got).all())
+    err = (got - ref_z).abs()
+    # same operands, fp32 accumulation in another order: at most the last bf16 bit of a result that sits on a rounding boundary
+    assert bool((err <= ref_z.abs() * 2.0 ** -7 + 1e-6).all()) and float((err > 0).float().mean()) < 0.02, (float(err.max()), float((err > 0).float().mean()))
+    dzb = to_blocked(dz, dev)
+    ws = torch.empty(L.ay_stem_train_wgrad_workspace_bytes(), device=dev, dtype=torch.uint8)
+    dw = torch.full((32, 3, 3, 3), 1.0, device=dev)
+    check(L.ay_stem_train_wgrad_bf16(ptr(xd), ptr(dzb), ptr(dw), 1, ptr(ws), ws.numel(), B, H, W, st), "stem wgrad")
+    dw2 = torch.full((32, 3, 3, 3), float("nan"), device=dev)
+    check(L.ay_stem_train_wgrad_bf16(ptr(xd), ptr(dzb), ptr(dw2), 0, ptr(ws), ws.numel(), B, H, W, st), "stem wgrad")
+    tol = 2e-5 * float(ref_dw.abs().max()) * np.sqrt(B * H * W / 1000.0) + 1e-4
+    assert float((dw2.cpu() - ref_dw).abs().max()) <= tol, (float((dw2.cpu() - ref_dw).abs().max()), tol)
+    assert float((dw.cpu() - 1.0 - ref_dw).abs().max()) <= tol + 1e-5 * float(ref_dw.abs().max())
+    dw3 = torch.empty_like(dw2)
+    check(L.ay_stem_train_wgrad_bf16(ptr(xd), ptr(dzb), ptr(dw3), 0, ptr(ws), ws.numel(), B, H, W, st), "stem wgrad")
+    assert torch.equal(dw2, dw3), "the filter gradient must not depend on the run"
+
+
 S2_DGRAD_CASES = [(32, 64, 72, True), (64, 128, 40, True), (128, 256, 36, False), (256, 512, 20, True), (512, 1024, 16, True), (16, 48, 24, False), (48, 80, 24, True)]
 
 
