@@ -322,7 +322,7 @@ __global__ void yolo_targets_pass1(const float* __restrict__ tgt, int nT, YoloGe
 //       [10] conf_obj_sum [11] conf_noobj_sum [12] conf50_sum [13] iou50*det [14] iou75*det
 __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __restrict__ tgt, YoloGeom g, const int* __restrict__ winner,
                                const unsigned* __restrict__ flags, const float* __restrict__ tcls, float* __restrict__ sums,
-                               float* __restrict__ dhead, int phase, float grad_scale, int box_loss) {
+                               float* __restrict__ dhead, int phase, float grad_scale, int box_loss, float* __restrict__ part) {
     // phase 0: accumulate sums (losses un-normalised + counts); phase 1: write dL/dhead using the counts in sums
     const int cells = g.B * g.A * g.G * g.G;
     const int K = 5 + g.C;
@@ -411,12 +411,25 @@ __global__ void yolo_loss_pass(const float* __restrict__ head, const float* __re
         }
     }
     if (phase == 0) {
+        // one partial row per workgroup, added up in a fixed order by yolo_loss_reduce (the per-wave float atomics this replaces --
+        // up to 24 576 waves on 4 hot addresses -- were most of the kernel's 250 us, and made the loss scalar depend on the run)
+        __shared__ float sm[4][16];
 #pragma unroll
         for (int k = 0; k < 15; ++k) {
             const float v = wave_sum(loc[k]);
-            if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sums[k], v);
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < 15) part[(size_t)blockIdx.x * 16 + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
     }
+}
+
+__global__ void yolo_loss_reduce(const float* __restrict__ part, int n_parts, float* __restrict__ sums) {
+    const int k = threadIdx.x;
+    if (k >= 15) return;
+    float s = 0.f;
+    for (int w = 0; w < n_parts; ++w) s += part[(size_t)w * 16 + k];
+    sums[k] = s;
 }
 
 // utils/utils.py:276-330 as dense tensors: everything the 10-tuple holds, from the pass-1 cell state (obj / noobj flags,
@@ -585,9 +598,12 @@ extern "C" int ay_slice_accumulate_f32(const float* dout, float* dsrc, int batch
     return AY_OK;
 }
 
+constexpr int YOLO_LOSS_WGS = 1024;   // workgroups of the two loss passes (grid-stride over the cells)
+
 extern "C" size_t ay_yolo_loss_workspace_bytes(int batch, int num_anchors, int num_classes, int grid) {
     const size_t cells = (size_t)batch * num_anchors * grid * grid;
-    return cells * 4 /*winner*/ + cells * 4 /*flags*/ + cells * num_classes * 4 /*tcls*/ + 64 * 4 /*sums*/;
+    return cells * 4 /*winner*/ + cells * 4 /*flags*/ + cells * num_classes * 4 /*tcls*/ + 64 * 4 /*sums*/ +
+           (size_t)YOLO_LOSS_WGS * 16 * 4 /*per-workgroup partial sums*/;
 }
 
 static int yolo_loss_impl(const float* head_nchw, const float* targets, int n_targets, int batch, int num_anchors, int num_classes,
@@ -626,10 +642,16 @@ static int yolo_loss_impl(const float* head_nchw, const float* targets, int n_ta
                            flags, tcls);
         AY_CHECK_LAUNCH("yolo_targets_pass1");
     }
-    const unsigned gr = gridn(cells);
-    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 0, grad_scale, box_loss);
+    unsigned gr = gridn(cells);
+    if (gr > (unsigned)YOLO_LOSS_WGS) gr = YOLO_LOSS_WGS;
+    float* part = sums + 64;
+    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 0, grad_scale, box_loss,
+                       part);
     AY_CHECK_LAUNCH("yolo_loss_pass(0)");
-    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 1, grad_scale, box_loss);
+    hipLaunchKernelGGL(yolo_loss_reduce, dim3(1), dim3(64), 0, st, part, (int)gr, sums);
+    AY_CHECK_LAUNCH("yolo_loss_reduce");
+    hipLaunchKernelGGL(yolo_loss_pass, dim3(gr), dim3(256), 0, st, head_nchw, targets, g, winner, flags, tcls, sums, dhead, 1, grad_scale, box_loss,
+                       part);
     AY_CHECK_LAUNCH("yolo_loss_pass(1)");
     if (hipMemcpyAsync(sums_out, sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("ay_yolo_loss_fwd_bwd: copy failed");
