@@ -92,6 +92,8 @@ _SIGS = {
     "ay_slice_accumulate_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ay_zero_insert_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ay_pack_dgrad_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_pack_batch_block": (_I, []),
+    "ay_pack_batch_bf16": (_I, [_P, _P, _I, _P]),
     "ay_stem_train_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ay_stem_train_wgrad_workspace_bytes": (C.c_size_t, []),
     "ay_stem_train_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _I, _I, _I, _P]),

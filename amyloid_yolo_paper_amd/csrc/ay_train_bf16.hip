@@ -353,6 +353,81 @@ __global__ void pack_dgrad_s2_weights_kernel(const float* __restrict__ w, uint16
     }
 }
 
+// ---- all filter images of a training step in ONE launch.  A step re-packs ~75 forward and ~70 data-gradient images (the weights
+// changed); as separate launches that is ~145 kernels of a few microseconds each -- 0.84 ms of a 23-ms step at 416^2 for 0.5 GB of
+// traffic.  ay_pack_batch_bf16 walks a job table (device memory, built once per weight layout by the caller): workgroup w takes
+// PACK_BLOCK consecutive elements of job work[w].job starting at work[w].first.
+constexpr int PACK_BLOCK = 2048;
+struct PackJob {             // mirrors ay_pack_job (include/amyloid_yolo.h)
+    const float* src;        // OIHW fp32 filters
+    uint16_t* dst;           // packed bf16 image
+    int32_t kind;            // 0: forward image (ay_pack_conv_weights_bf16), 1: data gradient (ay_pack_dgrad_weights_bf16), 2: stride-2 parity classes
+    int32_t cout, cout_pad, cin, cin_pad, ksize;
+    uint64_t total;          // elements of dst
+};
+struct PackWork {
+    uint32_t job, first_block;
+};
+
+__device__ __forceinline__ uint16_t pack_elem(const PackJob& jb, size_t i) {
+    const float* w = jb.src;
+    if (jb.kind == 0) {   // [cin/16][tap][half][cout_pad][8]; cin here = channels of the source tensor (multiple of 16)
+        const int kk2 = jb.ksize * jb.ksize;
+        const int j = (int)(i % 8);
+        size_t t = i / 8;
+        const int co = (int)(t % jb.cout_pad);
+        t /= jb.cout_pad;
+        const int half = (int)(t % 2);
+        t /= 2;
+        const int tap = (int)(t % kk2);
+        const int chunk = (int)(t / kk2);
+        const int ci = chunk * 16 + half * 8 + j;
+        return f2bf(co < jb.cout ? w[((size_t)co * jb.cin + ci) * kk2 + tap] : 0.f);
+    }
+    if (jb.kind == 1) {   // [cout_pad/16][tap][half][cin_pad][8], flipped taps, transposed channels
+        const int ks = jb.ksize, kk2 = ks * ks;
+        const int j = (int)(i % 8);
+        size_t t = i / 8;
+        const int ci = (int)(t % jb.cin_pad);
+        t /= jb.cin_pad;
+        const int half = (int)(t % 2);
+        t /= 2;
+        const int tap = (int)(t % kk2);
+        const int chunk = (int)(t / kk2);
+        const int co = chunk * 16 + half * 8 + j;
+        const int kh = tap / ks, kw = tap % ks;
+        return f2bf(co < jb.cout && ci < jb.cin ? w[(((size_t)co * jb.cin + ci) * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)] : 0.f);
+    }
+    // kind 2: [class][cout_pad/16][window tap][half][cin_pad][8]
+    const size_t per_class = (size_t)(jb.cout_pad / 16) * 4 * 2 * jb.cin_pad * 8;
+    const int cls = (int)(i / per_class);
+    size_t t = i % per_class;
+    const int j = (int)(t % 8);
+    t /= 8;
+    const int ci = (int)(t % jb.cin_pad);
+    t /= jb.cin_pad;
+    const int half = (int)(t % 2);
+    t /= 2;
+    const int tap = (int)(t % 4);
+    const int chunk = (int)(t / 4);
+    const int co = chunk * 16 + half * 8 + j;
+    const int py = cls >> 1, px = cls & 1, oy = tap >> 1, ox = tap & 1;
+    const int kh = py ? (oy ? 0 : 2) : (oy ? -1 : 1);
+    const int kw = px ? (ox ? 0 : 2) : (ox ? -1 : 1);
+    return f2bf(co < jb.cout && ci < jb.cin && kh >= 0 && kw >= 0 ? w[(((size_t)co * jb.cin + ci) * 3 + kh) * 3 + kw] : 0.f);
+}
+
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackJob* __restrict__ jobs, const PackWork* __restrict__ work) {
+    const PackWork wk = work[blockIdx.x];
+    const PackJob jb = jobs[wk.job];
+    const size_t base = (size_t)wk.first_block * PACK_BLOCK;
+#pragma unroll
+    for (int r = 0; r < PACK_BLOCK / 256; ++r) {
+        const size_t i = base + (size_t)r * 256 + threadIdx.x;
+        if (i < jb.total) jb.dst[i] = pack_elem(jb, i);
+    }
+}
+
 // chunks of one (image, plane) slice: every thread gets about two rounds of BN_UNROLL units where the plane allows, and the whole
 // grid stays below ~16k workgroups (each sums workgroup ends with one fp64 atomic per channel)
 static inline int bn_chunks(int batch, int planes, int HW) {
@@ -448,6 +523,16 @@ extern "C" int ay_zero_insert_bf16(const void* in, void* out, int batch, int cha
     const size_t units = (size_t)planes * ho * wo * 2;
     hipLaunchKernelGGL(zero_insert_kernel, dim3(gridu(units)), dim3(256), 0, S(stream), (const uint4*)in, (uint4*)out, planes, h, w, ho, wo);
     AY_CHECK_LAUNCH("zero_insert_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_pack_batch_block(void) { return ay::PACK_BLOCK; }
+
+extern "C" int ay_pack_batch_bf16(const void* jobs_device, const void* work_device, int n_work, ay_stream_t stream) {
+    static_assert(sizeof(PackJob) == 48 && sizeof(PackWork) == 8, "ay_pack_job / ay_pack_work layout");
+    AY_CHECK_ARG(jobs_device && work_device && n_work > 0, "ay_pack_batch_bf16: bad args");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)n_work), dim3(256), 0, S(stream), (const PackJob*)jobs_device, (const PackWork*)work_device);
+    AY_CHECK_LAUNCH("pack_batch_kernel");
     return AY_OK;
 }
 

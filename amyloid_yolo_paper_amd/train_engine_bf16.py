@@ -135,47 +135,69 @@ def _weights_signature(model):
 
 
 def _pack_weights(model, ctx):
-    """forward and data-gradient filter images of every convolution, once per optimiser step"""
+    """forward and data-gradient filter images of every convolution, once per optimiser step: ONE launch over a job table
+    (ay_pack_batch_bf16) that is rebuilt only when a weight tensor moved"""
     sig = _weights_signature(model)
     if ctx.packed_sig == sig:
         return ctx.packed
+    import numpy as np
     L = _lib.lib()
     st = _lib.stream_ptr()
     graph = model._graph
-    for i, e in enumerate(graph):
-        if e["type"] != "convolutional":
-            continue
-        conv = model.module_list[i][0]
-        cout, cin, k = e["cout"], e["cin"], e["k"]
-        w = conv.weight.detach()
-        rec = ctx.packed.setdefault(i, {})
-        cin_eff = cin
-        if e["src"] < 0 and _STEM_DIRECT and cout == 32 and cin == 3 and k == 3 and e["stride"] == 1:
-            # stem straight from the fp32 image (ay_stem_train_*): bf16 filters [32][32], index ci*9 + kh*3 + kw
-            w0f = ctx.get(("w0f", i), (32, 32), torch.float32, zero=True)
-            w0f[:, :27].copy_(w.reshape(32, 27))
-            w0 = ctx.get(("w0", i), (32, 32), torch.bfloat16)
-            w0.copy_(w0f)
-            rec.update(stem_w0=w0)
-        if e["src"] < 0:  # stem: filters get zero input channels 3..15
-            w16 = ctx.get(("w16", i), (cout, 16, k, k), torch.float32, zero=True)
-            w16[:, :cin].copy_(w)
-            w, cin_eff = w16, 16
-        cpad = _pad(cout, 32)
-        nbytes = L.ay_packed_weight_bytes(cpad, cin_eff, k)
-        fwd = ctx.get(("pk", i), (nbytes,), torch.uint8)
-        check(L.ay_pack_conv_weights_bf16(ptr(w), ptr(fwd), cout, cpad, cin_eff, k, st), "ay_pack_conv_weights_bf16")
-        rec.update(fwd=fwd, cpad=cpad, cin_eff=cin_eff)
-        if e["src"] >= 0:
+    convs = [(i, e, model.module_list[i][0]) for i, e in enumerate(graph) if e["type"] == "convolutional"]
+    table_key = tuple(c.weight.data_ptr() for _, _, c in convs)
+    if getattr(ctx, "pack_table_key", None) != table_key:
+        jobs, dev = [], convs[0][2].weight.device
+        for i, e, conv in convs:
+            cout, cin, k = e["cout"], e["cin"], e["k"]
+            w = conv.weight.detach()
+            rec = ctx.packed.setdefault(i, {})
+            cpad = _pad(cout, 32)
+            stem_direct = e["src"] < 0 and _STEM_DIRECT and cout == 32 and cin == 3 and k == 3 and e["stride"] == 1
+            if e["src"] < 0:
+                # the stem's generic-kernel images (16 zero-padded input channels) are built by the single-call path below; with the
+                # direct kernels only the [32][32] bf16 filter table exists
+                rec.update(cpad=cpad, cin_eff=16, stem_generic=not stem_direct)
+                if stem_direct:
+                    rec["stem_w0f"] = ctx.get(("w0f", i), (32, 32), torch.float32, zero=True)
+                    rec["stem_w0"] = ctx.get(("w0", i), (32, 32), torch.bfloat16)
+                else:
+                    rec["fwd"] = ctx.get(("pk", i), (L.ay_packed_weight_bytes(cpad, 16, k),), torch.uint8)
+                continue
+            fwd = ctx.get(("pk", i), (L.ay_packed_weight_bytes(cpad, cin, k),), torch.uint8)
+            rec.update(fwd=fwd, cpad=cpad, cin_eff=cin)
+            jobs.append((w.data_ptr(), fwd.data_ptr(), 0, cout, cpad, cin, 0, k, fwd.numel() // 2))
             cin_pad = _pad(cin, 32)
             if e["stride"] == 2 and _S2_DGRAD:
-                # four parity-class filter images for ay_conv_dgrad_s2_bf16 (no zero insertion)
                 dg = ctx.get(("pkd", i), (L.ay_packed_dgrad_s2_weight_bytes(cpad, cin_pad),), torch.uint8)
-                check(L.ay_pack_dgrad_s2_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cpad, cin, cin_pad, st), "ay_pack_dgrad_s2_weights_bf16")
+                jobs.append((w.data_ptr(), dg.data_ptr(), 2, cout, cpad, cin, cin_pad, 3, dg.numel() // 2))
             else:
                 dg = ctx.get(("pkd", i), ((cpad // 16) * k * k * 2 * cin_pad * 8 * 2,), torch.uint8, zero=True)  # rows of the pad planes stay zero
-                check(L.ay_pack_dgrad_weights_bf16(ptr(conv.weight.detach()), ptr(dg), cout, cin, cin_pad, k, st), "ay_pack_dgrad_weights_bf16")
+                cp16 = _pad(cout, 16)
+                jobs.append((w.data_ptr(), dg.data_ptr(), 1, cout, cp16, cin, cin_pad, k, (cp16 // 16) * k * k * 2 * cin_pad * 8))
             rec.update(dgrad=dg, cin_pad=cin_pad)
+        job_dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("kind", "<i4"), ("cout", "<i4"), ("cout_pad", "<i4"), ("cin", "<i4"),
+                           ("cin_pad", "<i4"), ("ksize", "<i4"), ("total", "<u8")])
+        assert job_dt.itemsize == 48
+        ja = np.array(jobs, dtype=job_dt)
+        blk = L.ay_pack_batch_block()
+        work = np.array([(j, b) for j, jb in enumerate(jobs) for b in range((jb[8] + blk - 1) // blk)], dtype=np.dtype([("job", "<u4"), ("first", "<u4")]))
+        ctx.pack_jobs = torch.from_numpy(ja.view(np.uint8).copy()).to(dev)
+        ctx.pack_work = torch.from_numpy(work.view(np.uint8).copy()).to(dev)
+        ctx.pack_n_work = int(work.shape[0])
+        ctx.pack_table_key = table_key
+    check(L.ay_pack_batch_bf16(ptr(ctx.pack_jobs), ptr(ctx.pack_work), ctx.pack_n_work, st), "ay_pack_batch_bf16")
+    for i, e, conv in convs:
+        if e["src"] >= 0:
+            continue
+        rec, w = ctx.packed[i], conv.weight.detach()
+        if rec.get("stem_w0") is not None:
+            rec["stem_w0f"][:, :27].copy_(w.reshape(32, 27))
+            rec["stem_w0"].copy_(rec["stem_w0f"])
+        else:  # stem through the generic kernels: filters get zero input channels 3..15
+            w16 = ctx.get(("w16", i), (e["cout"], 16, e["k"], e["k"]), torch.float32, zero=True)
+            w16[:, : e["cin"]].copy_(w)
+            check(L.ay_pack_conv_weights_bf16(ptr(w16), ptr(rec["fwd"]), e["cout"], rec["cpad"], 16, e["k"], st), "ay_pack_conv_weights_bf16")
     ctx.packed_sig = sig
     return ctx.packed
 
@@ -228,6 +250,7 @@ def train_forward_bf16(model, x, targets):
 
     row = 0
     sums_all = []
+    nbt = []   # BatchNorm modules that ran: their num_batches_tracked counters are views of one flat tensor, bumped once per forward
     prof = getattr(model, "_train_prof", None)
     for i, e in enumerate(graph):
         t = e["type"]
@@ -280,7 +303,7 @@ def train_forward_bf16(model, x, targets):
             check(L.ay_bn_train_fwd_bf16(ptr(z), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var),
                                          C.c_float(bn.momentum), C.c_float(bn.eps), int(e["leaky"]), ptr(skip), ptr(y), ptr(mean), ptr(invstd),
                                          ptr(ws), B, cout, hout, hout, st), "ay_bn_train_fwd_bf16")
-            bn.num_batches_tracked += 1
+            nbt.append(bn)
             rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, ws=ws)
             stt.conv[i] = rec
             if fuse:
@@ -329,6 +352,17 @@ def train_forward_bf16(model, x, targets):
                 stt.dhead[i] = dhead
                 sums_all.append((y, sums, G))
             val[i] = head
+    if nbt:
+        # num_batches_tracked += 1 for every BatchNorm that ran (models.py:43 semantics of nn.BatchNorm2d in train mode): the counters
+        # are re-pointed once to views of one flat int64 tensor, so a step costs one add instead of 72 launches
+        flat = getattr(model, "_nbt_flat", None)
+        if (flat is None or flat.numel() != len(nbt) or flat.device != dev or nbt[0].num_batches_tracked.data_ptr() != flat[0].data_ptr()
+                or nbt[-1].num_batches_tracked.data_ptr() != flat[-1].data_ptr()):
+            flat = torch.stack([b.num_batches_tracked.detach().to(dev) for b in nbt])
+            for k_, b in enumerate(nbt):
+                b._buffers["num_batches_tracked"] = flat[k_]
+            model._nbt_flat = flat
+        flat.add_(1)
     loss = None
     if tg is not None:
         allsums = torch.stack([s for _, s, _ in sums_all])

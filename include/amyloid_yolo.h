@@ -266,6 +266,23 @@ int ay_zero_insert_bf16(const void* in, void* out, int batch, int channels, int 
 /* filters that make ay_conv_fwd_bf16 compute the data gradient: W'[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw], packed
  * [ceil(cout/16)][k*k][2][cin_pad][8]; use with desc{cin=ceil16(cout), cout=cin, cout_pad=cin_pad, stride 1}. */
 int ay_pack_dgrad_weights_bf16(const float* w_oihw, void* packed, int cout, int cin, int cin_pad, int ksize, ay_stream_t stream);
+/* Every filter image a training step needs, re-packed in ONE launch after the optimiser moved the weights (the reference has no
+ * counterpart: its convolutions read nn.Conv2d.weight directly; this replaces ~145 ay_pack_*_bf16 launches per step).  `jobs` and
+ * `work` live in DEVICE memory and are built once per weight layout: job j packs `total` elements of image kind `kind` (0 =
+ * ay_pack_conv_weights_bf16, `cin` = channels of the source tensor; 1 = ay_pack_dgrad_weights_bf16; 2 =
+ * ay_pack_dgrad_s2_weights_bf16) exactly as the single calls do; work item w = (job, first_block) covers elements
+ * [first_block * ay_pack_batch_block(), +ay_pack_batch_block()) of that job. */
+typedef struct ay_pack_job {
+    const float* src;
+    void* dst;
+    int32_t kind, cout, cout_pad, cin, cin_pad, ksize;
+    uint64_t total;
+} ay_pack_job;
+typedef struct ay_pack_work {
+    uint32_t job, first_block;
+} ay_pack_work;
+int ay_pack_batch_block(void);
+int ay_pack_batch_bf16(const void* jobs_device, const void* work_device, int n_work, ay_stream_t stream);
 /* The stem Conv2d(3, 32, 3, 1, 1) (models.py:33-41, layer 0) on the bf16 training path, straight from the fp32 NCHW image (W % 4 == 0,
  * 16-byte aligned): forward z = bf16(conv(bf16(x), bf16(w))) with fp32 accumulation -> blocked bf16 [B][2][H][W][16]
  * (w_bf16: [32][32] bf16, index ci*9 + kh*3 + kw, entries 27..31 unused), and the filter gradient dW[32][3][3][3] (fp32,
