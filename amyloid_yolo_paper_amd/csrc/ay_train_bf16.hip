@@ -121,33 +121,16 @@ __global__ void __launch_bounds__(256) bn_sums_kernel(const uint4* __restrict__ 
 }
 
 // finalize forward statistics: mean, invstd, running stats (PyTorch semantics)
-__global__ void bn_finalize_fwd_kernel(const double* sums, double n, float eps, float momentum, float* running_mean, float* running_var,
-                                       float* save_mean, float* save_invstd, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = sums[c] / n;
-    double var = sums[C + c] / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
-}
-
-// accumulate != 0: the parameter gradients are ADDED to dgamma / dbeta (gradient accumulation over batches, train.py:116-119)
-__global__ void bn_finalize_bwd_kernel(const double* sums, float* dgamma, float* dbeta, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
-}
-
 // y = bf16( leaky(gamma * (z - mean) * invstd + beta) [+ skip] )
-__global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__ z, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int leaky, const uint4* __restrict__ skip,
-                                                       uint4* __restrict__ y, int C, int CP, int HW, int chunks) {
+// The batch statistics are finalised HERE, from the per-channel sums: every workgroup derives mean / invstd of its 16 channels the
+// same way (fp64, then one rounding to fp32), and workgroup 0 of a plane also writes save_mean / save_invstd and updates the running
+// statistics (PyTorch momentum semantics, models.py:43) -- the separate one-workgroup finalize launch per layer is gone (72 launches
+// of ~5 us per step: small tensors at 416^2 are launch-bound).
+__global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__ z, const double* __restrict__ sums, double n, float eps,
+                                                       float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
+                                                       const uint4* __restrict__ skip, uint4* __restrict__ y, int C, int CP, int HW, int chunks) {
     const int plane = blockIdx.y;
     const int half = threadIdx.x & 1;
     const int c0 = plane * 16 + half * 8;
@@ -155,10 +138,20 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const uint4* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c0 + j < C ? c0 + j : C - 1;
-        mu[j] = mean[c];
-        is[j] = invstd[c];
+        const double mean = sums[c] / n;
+        double var = sums[C + c] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mu[j] = (float)mean;
+        is[j] = (float)(1.0 / sqrt(var + (double)eps));
         ga[j] = gamma[c];
         be[j] = beta[c];
+        if (blockIdx.x == 0 && threadIdx.x < 2 && c0 + j < C) {   // one thread per channel half
+            save_mean[c] = mu[j];
+            save_invstd[c] = is[j];
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
     }
     const int units = HW * 2;
     const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
@@ -199,7 +192,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int leaky,
                                                            const double* __restrict__ sums, float n, uint4* __restrict__ dz, int C, int CP,
-                                                           int HW, int chunks) {
+                                                           int HW, int chunks, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
     const int plane = blockIdx.y;
     const int half = threadIdx.x & 1;
     const int c0 = plane * 16 + half * 8;
@@ -213,6 +207,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint4* __restri
         be[j] = beta[c];
         sb[j] = (float)sums[c];
         sg[j] = (float)sums[C + c];
+        // the parameter gradients (accumulate != 0: ADDED, gradient accumulation over batches, train.py:116-119): workgroup 0 of the plane
+        if (blockIdx.x == 0 && threadIdx.x < 2 && c0 + j < C) {
+            dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sb[j];
+            dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sg[j];
+        }
     }
     const int units = HW * 2;
     const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
@@ -471,11 +470,9 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
     hipLaunchKernelGGL(bn_sums_kernel<false>, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)z, nullptr, nullptr, nullptr, nullptr,
                        nullptr, 0, sums_ws, channels, HW, ch);
     AY_CHECK_LAUNCH("bn_sums_kernel");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, (double)batch * HW, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd, channels);
-    AY_CHECK_LAUNCH("bn_finalize_fwd_kernel");
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)z, save_mean, save_invstd, gamma, beta,
-                       leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW, ch);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)z, sums_ws, (double)batch * HW, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd, gamma, beta, leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW,
+                       ch);
     AY_CHECK_LAUNCH("bn_apply_kernel");
     return AY_OK;
 }
@@ -494,10 +491,9 @@ extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const flo
     hipLaunchKernelGGL(bn_sums_kernel<true>, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean, save_invstd,
                        gamma, beta, leaky, sums_ws, channels, HW, ch);
     AY_CHECK_LAUNCH("bn_sums_kernel<bwd>");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, sums_ws, dgamma, dbeta, channels, accumulate);
-    AY_CHECK_LAUNCH("bn_finalize_bwd_kernel");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, st, (const uint4*)dy, (const uint4*)z, save_mean,
-                       save_invstd, gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW, ch);
+                       save_invstd, gamma, beta, leaky, sums_ws, (float)((double)batch * HW), (uint4*)dz, channels, CP, HW, ch, dgamma, dbeta,
+                       accumulate);
     AY_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return AY_OK;
 }
