@@ -34,6 +34,19 @@ struct WgradArgs {
 };
 
 __device__ __forceinline__ int swz(int px) { return px ^ (((px >> 3) & 1) << 2); }
+#ifdef AY_PHASE_CLOCK
+// instrumented build only: 100 MHz ticks of wave 0 summed over workgroups: [0] stage body (reads + MFMAs + DMA issue), [1] wait for the
+// next stage's DMA, [2] barrier, [3] epilogue, [4] K steps, [5] workgroups, [6] prologue
+__device__ unsigned long long g_wgrad_ticks[8];
+#define WG_TICK(k)                                      \
+    if (wave == 0) {                                    \
+        const unsigned long long t_ = wall_clock64();   \
+        wtk[k] += t_ - wtk_last;                        \
+        wtk_last = t_;                                  \
+    }
+#else
+#define WG_TICK(k)
+#endif
 
 // SEGS: row segments per K step (and per barrier).  1x1 layers have 4 MFMAs per wave and segment: one segment per step left the
 // kernel barrier-bound (173 us per launch on average at B=32 / 1024^2 against ~70 us of HBM time); they take 4 segments per step
@@ -64,7 +77,7 @@ __global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16
     constexpr int STAGING_BYTES = 8 * 16 * 16 * KK2 * 4;   // the epilogue's transposes reuse the stage buffers
     constexpr int LDS_BYTES = (RING_BYTES > STAGING_BYTES ? RING_BYTES : STAGING_BYTES) + 1024;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(NBUF == 3 || NBUF == 4, "ring depth");
+    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
 
@@ -216,6 +229,9 @@ __global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+#ifdef AY_PHASE_CLOCK
+    unsigned long long wtk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wtk_last = wall_clock64();
+#endif
     int cur = 0, nxt = (NBUF - 1) % NBUF;
     constexpr int NGROUP = SEGS * KK2;   // MFMA groups (one tap of one segment: COW MFMAs) per stage; the stage's PWS pieces are spread over them
     for (int k = 0; k < nstep; ++k) {
@@ -279,13 +295,19 @@ __global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16
         else
             stage_body(std::integral_constant<int, 0>{});
         if (do_issue) ++issued;
+        WG_TICK(0)
         if (k + 1 < nstep) {
             wait_landed(issued - (k + 1) - 1);  // stages issued beyond k+1 may stay in flight
+            WG_TICK(1)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            WG_TICK(2)
         }
         if (++cur == NBUF) cur = 0;
     }
+#ifdef AY_PHASE_CLOCK
+    if (wave == 0) wtk[4] += nstep, wtk[5] += 1;
+#endif
 
     // ---- epilogue: the workgroup's partial filters go to its split-K slab (plain contiguous stores) or, without a workspace, to
     // dW by fp32 atomics; either way coalesced.  D of one 16x16 tile: row (co) = 4*(lane>>4) + reg, col (ci) = lane & 15.
@@ -321,6 +343,11 @@ __global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef AY_PHASE_CLOCK
+    WG_TICK(3)
+    if (wave == 0 && lane == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_wgrad_ticks[k], wtk[k]);
+#endif
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], s in ascending order: the same bits on every run.  Replaces ks x |dW| fp32
@@ -348,6 +375,7 @@ constexpr int WGRAD_SEGS_1X1 = 4;
 #ifndef AY_WGRAD_SEGS_3X3
 #define AY_WGRAD_SEGS_3X3 2
 #endif
+constexpr int WGRAD_NBUF_3X3 = AY_WGRAD_SEGS_3X3 == 1 ? 4 : (AY_WGRAD_SEGS_3X3 == 2 ? 3 : 2);   // 6 segment buffers (126 KiB) either way
 constexpr int WGRAD_SEGS_3X3 = AY_WGRAD_SEGS_3X3;   // 3x3 stride 1: 2 segments per K step from a ring of 3 stages (126 KiB)
 
 // narrow layers (see the kernel template): 3x3 with at most 4 x 2 planes, 1x1 with at most 2 x 4
@@ -447,12 +475,24 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
         else
             hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1, 3, 2, 4>), grid, block, 0, st, a);
     } else if (d->ksize == 3 && d->stride == 1)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_SEGS_3X3 == 1 ? 4 : 3>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_NBUF_3X3>), grid, block, 0, st, a);
     else if (d->ksize == 3)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2>), grid, block, 0, st, a);
     else
         hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1, 3>), grid, block, 0, st, a);
     AY_CHECK_LAUNCH("wgrad_bf16_kernel");
+#ifdef AY_PHASE_CLOCK
+    if (getenv("AY_DBG") && (atoi(getenv("AY_DBG")) & 8)) {
+        unsigned long long t[8] = {0}, z[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_wgrad_ticks), sizeof(t));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_ticks), z, sizeof(z));
+        if (t[4])
+            fprintf(stderr, "[ay wgrad] k%d s%d %d->%d @%d ks %lld: per K step (us): body %.2f, dma wait %.2f, barrier %.2f; per workgroup: %.0f steps, epilogue %.1f us\n",
+                    d->ksize, d->stride, d->cin, d->cout, d->hout, ks, t[0] * 0.01 / t[4], t[1] * 0.01 / t[4], t[2] * 0.01 / t[4], (double)t[4] / t[5],
+                    t[3] * 0.01 / t[5]);
+    }
+#endif
     if (slabs) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_elems + 1023) / 1024)), dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks,
                            accumulate);
