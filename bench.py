@@ -322,7 +322,7 @@ def bench_train(a, rank, local_rank, world, dev):
             "traffic": None, "kernel": "ay::wgrad_bf16_kernel<3,1> (weight gradient of the 3x3 s1 family: the largest share of the step)",
             "launches_per_step": len(prof["wgrad"]) // a.steps, "avg_launch_ms": round(ms_w / len(prof["wgrad"]), 4),
             "share_of_step": round(ms_w / a.steps / (1e3 * elapsed / a.steps), 3),
-            "conv_family": {"kernel": "ay::conv3x3_m16_ring_kernel (forward + data gradient of the same layers)",
+            "conv_family": {"kernel": "ay::conv3x3_m16_ring_kernel (forward + data gradient of the same layers; grids below 16 rows or canvas-tiled ones -- the 416-px maps -- run on ay::conv_bf16_ring_kernel<3,1,128,...>)",
                             "achieved": round(fl_c * a.steps / (ms_c * 1e-3) / 1e12, 1), "frac": round(fl_c * a.steps / (ms_c * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                             "launches_per_step": len(prof["conv"]) // a.steps, "share_of_step": round(ms_c / a.steps / (1e3 * elapsed / a.steps), 3)},
         }
