@@ -259,13 +259,15 @@ def test_stem_and_concat(dev):
     assert torch.equal(got.cpu(), ref)
 
 
-def test_stem_fused_kernel(dev):
+@pytest.mark.parametrize("H", [72, 70, 136], ids=lambda h: f"s{h}")
+def test_stem_fused_kernel(dev, H):
     """fused layer 0 + layer 1 vs torch-CPU with the same rounding points (bf16 image/filters, fp32 accumulate, bf16
-    intermediate, bf16 output).  Ragged size (72 -> 36: not a multiple of the 8x32 tile)."""
+    intermediate, bf16 output).  Ragged sizes (72 -> 36: not a multiple of the tile; 136: several tiles per row); 70 is not a
+    multiple of 4 and takes the round-1 kernel (4-byte tile DMA), the others the pipelined v2 kernel (16-byte descriptor DMA)."""
     L = _lib.lib()
     st = _lib.stream_ptr()
     g = torch.Generator().manual_seed(11)
-    B, H = 2, 72
+    B = 2
     x = torch.rand(B, 3, H, H, generator=g)
     w0 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
     s0, t0 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
