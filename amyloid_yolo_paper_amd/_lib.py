@@ -95,6 +95,9 @@ _SIGS = {
     "ay_pack_batch_block": (_I, []),
     "ay_pack_batch_bf16": (_I, [_P, _P, _I, _P]),
     "ay_stem_train_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ay_stem_train_stats_workspace_bytes": (C.c_size_t, []),
+    "ay_stem_train_fwd_stats_bf16": (_I, [_P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _P]),
+    "ay_bn_train_apply_bf16": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_stem_train_wgrad_workspace_bytes": (C.c_size_t, []),
     "ay_stem_train_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _I, _I, _I, _P]),
     "ay_packed_dgrad_s2_weight_bytes": (C.c_size_t, [_I, _I]),

@@ -49,6 +49,7 @@ struct Args {
     uint8_t* z;              // forward: [B][2][H][W][16] bf16
     const uint8_t* dz;       // weight gradient: [B][2][H][W][16] bf16
     float* slab;             // weight gradient: [gridDim.x][864] partial filters in dW order
+    float* stat_slab;        // forward, optional: [gridDim.x][64] per-workgroup (sum z[32], sum z^2[32]) of the ROUNDED outputs it stored
 };
 
 struct Coord {
@@ -67,7 +68,8 @@ __device__ __forceinline__ Coord coord_of(const Args& a, unsigned it) {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: 8 waves, each two blocks of 32 pixels per item (v_mfma_f32_32x32x16_bf16: rows = 32 filters, columns = 32 pixels, K = 32
 // tap slots in two steps); the result is rounded once and stored through the lane-pair swap of the inference epilogues.
-__global__ void __launch_bounds__(512) stem_train_fwd_kernel(stemtr::Args a, int n_items) {
+template <bool STATS>
+__global__ void __launch_bounds__(512, 4) stem_train_fwd_kernel(stemtr::Args a, int n_items) {
     using namespace stemtr;
     constexpr int NIB = 3;
     constexpr int OFF_SCRATCH = NIB * IMG_BYTES;
@@ -78,7 +80,10 @@ __global__ void __launch_bounds__(512) stem_train_fwd_kernel(stemtr::Args a, int
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int per_xcd = (n_items + 7) >> 3;
     const int first = xcd * per_xcd, last = min(first + per_xcd, n_items);
-    if (first + slot >= last) return;
+    if (first + slot >= last) {
+        if (STATS && tid < 64) a.stat_slab[(size_t)blockIdx.x * 64 + tid] = 0.f;
+        return;
+    }
     const int nk = (last - (first + slot) + slots - 1) / slots;
     auto item_at = [&](int k) { return (unsigned)(first + slot + k * slots); };
     const unsigned lds_base = lds_addr_of(lds);
@@ -135,6 +140,12 @@ __global__ void __launch_bounds__(512) stem_train_fwd_kernel(stemtr::Args a, int
         pbase1[j] = px + hh * 2 * IW;
     }
     const unsigned out_plane_bytes = (unsigned)plane_elems * 32u;
+    // BatchNorm batch statistics of this layer (models.py:43 in train mode) gathered where the outputs are produced: a workgroup keeps
+    // per-lane sums of its 16 channels over ALL its items (a few hundred) and reduces them once at the end -- the separate pass that
+    // re-reads the 2.1 GB of z (B=32 / 1024^2) is not needed.  The sums are over the bf16-rounded values, as the separate pass sees them.
+    float st1[16], st2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st1[r] = st2[r] = 0.f;
 
     Coord cA = coord_of(a, item_at(0)), cB = cA;
     issue_image(cA, 0);
@@ -184,6 +195,15 @@ __global__ void __launch_bounds__(512) stem_train_fwd_kernel(stemtr::Args a, int
                 const int o = qp * 8;
                 const unsigned ax = pack2bf2(f32x2{acc[o + 0], acc[o + 1]}), ay_ = pack2bf2(f32x2{acc[o + 2], acc[o + 3]});
                 const unsigned bx = pack2bf2(f32x2{acc[o + 4], acc[o + 5]}), by = pack2bf2(f32x2{acc[o + 6], acc[o + 7]});
+                if (STATS && ok) {   // register o + i holds channel (i & 3) + 8 (i >> 2) + 4 hh + 16 qp of this lane's pixel
+                    const f32x2 r01 = bf2f2(ax), r23 = bf2f2(ay_), r45 = bf2f2(bx), r67 = bf2f2(by);
+                    const float rv[8] = {r01[0], r01[1], r23[0], r23[1], r45[0], r45[1], r67[0], r67[1]};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        st1[o + i] += rv[i];
+                        st2[o + i] += rv[i] * rv[i];
+                    }
+                }
                 auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0[0], r1[0], r0[1], r1[1]}, orsrc, vo + (unsigned)qp * out_plane_bytes, 0, 0);
@@ -202,6 +222,44 @@ __global__ void __launch_bounds__(512) stem_train_fwd_kernel(stemtr::Args a, int
         cA = cB;
         cB = cC;
     }
+    if constexpr (STATS) {
+        // lanes of one half hold the same 16 channels (register r: channel (r & 3) + 8 ((r >> 2) & 1) + 4 hh + 16 (r >> 3)) for 32
+        // different pixels: butterfly over the 32 lanes, then the 8 waves through LDS, one row of 64 floats per workgroup
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                st1[r] += __shfl_xor(st1[r], off);
+                st2[r] += __shfl_xor(st2[r], off);
+            }
+        }
+        __syncthreads();   // the tile buffers are dead
+        float* red = reinterpret_cast<float*>(lds);   // [wave 8][64]
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh + 16 * (r >> 3);
+                red[wave * 64 + ch] = st1[r];
+                red[wave * 64 + 32 + ch] = st2[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w * 64 + tid];
+            a.stat_slab[(size_t)blockIdx.x * 64 + tid] = v;
+        }
+    }
+}
+
+// sums[c] = sum z, sums[32 + c] = sum z^2 over the whole batch, fp64, workgroup rows added in a fixed order
+__global__ void stem_stats_reduce_kernel(const float* __restrict__ slab, int n_rows, double* __restrict__ sums) {
+    const int i = threadIdx.x;
+    if (i >= 64) return;
+    double s = 0.0;
+    for (int k = 0; k < n_rows; ++k) s += (double)slab[(size_t)k * 64 + i];
+    sums[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -417,8 +475,30 @@ extern "C" int ay_stem_train_fwd_bf16(const float* x_nchw, const void* w_bf16, v
     AY_CHECK_ARG(stem_train_setup(a, x_nchw, batch, h, w, &n_items, &grid, 2), "ay_stem_train_fwd_bf16: grid");   // 31 KiB of LDS: two per CU
     a.w0 = (const uint16_t*)w_bf16;
     a.z = (uint8_t*)z_blocked;
-    hipLaunchKernelGGL(stem_train_fwd_kernel, dim3(grid), dim3(512), 0, S(stream), a, (int)n_items);
+    hipLaunchKernelGGL(stem_train_fwd_kernel<false>, dim3(grid), dim3(512), 0, S(stream), a, (int)n_items);
     AY_CHECK_LAUNCH("stem_train_fwd_kernel");
+    return AY_OK;
+}
+
+extern "C" size_t ay_stem_train_stats_workspace_bytes(void) { return (size_t)2 * conv_num_cus() * 64 * sizeof(float); }
+
+extern "C" int ay_stem_train_fwd_stats_bf16(const float* x_nchw, const void* w_bf16, void* z_blocked, double* sums /* 64 doubles */, void* workspace,
+                                            size_t workspace_bytes, int batch, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(w_bf16 && z_blocked && sums && workspace, "ay_stem_train_fwd_stats_bf16: null");
+    if (int rc = stem_train_args_ok(x_nchw, batch, h, w, "ay_stem_train_fwd_stats_bf16")) return rc;
+    stemtr::Args a{};
+    long long n_items;
+    unsigned grid;
+    AY_CHECK_ARG(stem_train_setup(a, x_nchw, batch, h, w, &n_items, &grid, 2), "ay_stem_train_fwd_stats_bf16: grid");
+    AY_CHECK_ARG(workspace_bytes >= (size_t)grid * 64 * sizeof(float), "ay_stem_train_fwd_stats_bf16: workspace");
+    a.w0 = (const uint16_t*)w_bf16;
+    a.z = (uint8_t*)z_blocked;
+    a.stat_slab = (float*)workspace;
+    hipStream_t st = S(stream);
+    hipLaunchKernelGGL(stem_train_fwd_kernel<true>, dim3(grid), dim3(512), 0, st, a, (int)n_items);
+    AY_CHECK_LAUNCH("stem_train_fwd_kernel");
+    hipLaunchKernelGGL(stem_stats_reduce_kernel, dim3(1), dim3(64), 0, st, a.stat_slab, (int)grid, sums);
+    AY_CHECK_LAUNCH("stem_stats_reduce_kernel");
     return AY_OK;
 }
 

@@ -477,6 +477,20 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
     return AY_OK;
 }
 
+// the same layer when the producer of z already left (sum z, sum z^2) in sums_ws (ay_stem_train_fwd_stats_bf16): the apply pass alone
+extern "C" int ay_bn_train_apply_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                      float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                                      const double* sums_ws /* 2*C doubles, filled */, int batch, int channels, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(z && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && sums_ws, "ay_bn_train_apply_bf16: null");
+    const int CP = (channels + 15) / 16, HW = h * w;
+    const int ch = bn_chunks(batch, CP, HW);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * ch, CP), dim3(256), 0, S(stream), (const uint4*)z, sums_ws, (double)batch * HW, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd, gamma, beta, leaky, (const uint4*)skip, (uint4*)y, channels, CP, HW,
+                       ch);
+    AY_CHECK_LAUNCH("bn_apply_kernel");
+    return AY_OK;
+}
+
 extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
                                         const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
                                         int accumulate, int batch, int channels, int h, int w, ay_stream_t stream) {

@@ -289,8 +289,17 @@ def train_forward_bf16(model, x, targets):
             bn = m[1]
             assert cout % 32 == 0, f"layer {i}: the bf16 training path needs BN layers with a multiple of 32 filters (got {cout})"
             z = blocked(("z", i), cout, hout, pad=32)
+            stats_done = False
             if stem_direct:
-                check(L.ay_stem_train_fwd_bf16(ptr(x), ptr(pk["stem_w0"]), ptr(z), B, hin, hin, st), "ay_stem_train_fwd_bf16")
+                # forward + the layer's BatchNorm batch statistics in one kernel (the sums land in the layer's fp64 workspace)
+                ws = ctx.get(("ws", i), (2 * cout,), torch.float64)
+                nws = L.ay_stem_train_stats_workspace_bytes()
+                sws = ctx.buf.get("stem_stats_ws")
+                if sws is None or sws.numel() < nws:
+                    sws = ctx.buf["stem_stats_ws"] = torch.empty(nws, device=dev, dtype=torch.uint8)
+                check(L.ay_stem_train_fwd_stats_bf16(ptr(x), ptr(pk["stem_w0"]), ptr(z), ptr(ws), ptr(sws), sws.numel(), B, hin, hin, st),
+                      "ay_stem_train_fwd_stats_bf16")
+                stats_done = True
             else:
                 with _Timed(prof, "conv", _family(e)):
                     check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(pk["fwd"]), ptr(ones), ptr(zeros), None, ptr(z), st), "ay_conv_fwd_bf16")
@@ -300,9 +309,10 @@ def train_forward_bf16(model, x, targets):
             mean = ctx.get(("mean", i), (cout,), torch.float32)
             invstd = ctx.get(("invstd", i), (cout,), torch.float32)
             ws = ctx.get(("ws", i), (2 * cout,), torch.float64)
-            check(L.ay_bn_train_fwd_bf16(ptr(z), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var),
-                                         C.c_float(bn.momentum), C.c_float(bn.eps), int(e["leaky"]), ptr(skip), ptr(y), ptr(mean), ptr(invstd),
-                                         ptr(ws), B, cout, hout, hout, st), "ay_bn_train_fwd_bf16")
+            check((L.ay_bn_train_apply_bf16 if stats_done else L.ay_bn_train_fwd_bf16)(
+                ptr(z), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), C.c_float(bn.momentum),
+                C.c_float(bn.eps), int(e["leaky"]), ptr(skip), ptr(y), ptr(mean), ptr(invstd), ptr(ws), B, cout, hout, hout, st),
+                "ay_bn_train_fwd_bf16")
             nbt.append(bn)
             rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, ws=ws)
             stt.conv[i] = rec

@@ -290,6 +290,15 @@ int ay_pack_batch_bf16(const void* jobs_device, const void* work_device, int n_w
  * `workspace` (ay_stem_train_wgrad_workspace_bytes()) and are added in a fixed order.  What loss.backward() (train.py:113)
  * computes for that layer, on bf16-rounded operands. */
 int ay_stem_train_fwd_bf16(const float* x_nchw, const void* w_bf16, void* z_blocked, int batch, int h, int w, ay_stream_t stream);
+/* ... and the layer's BatchNorm batch statistics gathered where z is produced ("stats reduce fused with the conv
+ * epilogue"): sums[0..31] = sum z, sums[32..63] = sum z^2 over the batch (of the bf16-rounded values, fp64, fixed summation order), to
+ * be followed by ay_bn_train_apply_bf16 -- ay_bn_train_fwd_bf16 without its statistics pass. */
+size_t ay_stem_train_stats_workspace_bytes(void);
+int ay_stem_train_fwd_stats_bf16(const float* x_nchw, const void* w_bf16, void* z_blocked, double* sums, void* workspace, size_t workspace_bytes,
+                                 int batch, int h, int w, ay_stream_t stream);
+int ay_bn_train_apply_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                           float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd, const double* sums_ws,
+                           int batch, int channels, int h, int w, ay_stream_t stream);
 size_t ay_stem_train_wgrad_workspace_bytes(void);
 int ay_stem_train_wgrad_bf16(const float* x_nchw, const void* dz_blocked, float* dw_oihw, int accumulate, void* workspace,
                              size_t workspace_bytes, int batch, int h, int w, ay_stream_t stream);

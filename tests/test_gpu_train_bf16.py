@@ -146,6 +146,15 @@ def test_stem_train_kernels(shape):
     err = (got - ref_z).abs()
     # same operands, fp32 accumulation in another order: at most the last bf16 bit of a result that sits on a rounding boundary
     assert bool((err <= ref_z.abs() * 2.0 ** -7 + 1e-6).all()) and float((err > 0).float().mean()) < 0.02, (float(err.max()), float((err > 0).float().mean()))
+    # the same forward with the BatchNorm statistics gathered in the kernel: identical z, sums = those of the rounded outputs
+    zb2 = torch.full((B, 2, H, W, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+    sums = torch.full((64,), float("nan"), device=dev, dtype=torch.float64)
+    sws = torch.empty(L.ay_stem_train_stats_workspace_bytes(), device=dev, dtype=torch.uint8)
+    check(L.ay_stem_train_fwd_stats_bf16(ptr(xd), ptr(w0d), ptr(zb2), ptr(sums), ptr(sws), sws.numel(), B, H, W, st), "stem fwd + stats")
+    assert torch.equal(zb2, zb)
+    g64 = got.double()
+    ref_sums = torch.cat([g64.sum((0, 2, 3)), (g64 * g64).sum((0, 2, 3))])
+    assert float((sums.cpu() - ref_sums).abs().max()) <= 1e-5 * float(ref_sums.abs().max()), (sums.cpu(), ref_sums)
     dzb = to_blocked(dz, dev)
     ws = torch.empty(L.ay_stem_train_wgrad_workspace_bytes(), device=dev, dtype=torch.uint8)
     dw = torch.full((32, 3, 3, 3), 1.0, device=dev)
