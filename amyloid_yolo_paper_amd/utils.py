@@ -171,6 +171,20 @@ def nms_device(pred_dev, conf_thres, nms_thres, max_det, slot=0):
     return rows, keep, count, cand
 
 
+def graph_replay(graph):
+    """Replay a captured `torch.cuda.CUDAGraph` of library calls and FENCE it: an event recorded on the current stream behind the
+    replay, waited for by that same stream.  On ROCm 7.2 / PyTorch 2.10 work launched into a stream after `hipGraphLaunch` (and
+    stream / device synchronisation) does not wait for the graph's last node; an event recorded on the stream does.  Without the
+    fence the next step overlaps the tail of the replay -- the persistent kernels assume a launch starts after its predecessor
+    on the stream has drained (arena reuse, per-launch counter sets) -- which gave inconsistent detections and, with dynamic item
+    dealing, a GPU memory fault."""
+    graph.replay()
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.current_stream().wait_event(ev)
+    return ev
+
+
 def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.4):
     """Reference ``utils/utils.py:235-273``: conf filter, score sort, greedy class-aware suppression with
     confidence-weighted merge.  ``prediction[..., :4]`` becomes corners IN PLACE, as in the reference.

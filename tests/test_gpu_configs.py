@@ -67,20 +67,17 @@ def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir):
     assert np.quantile(dconf, 0.99) <= 2e-2 and np.quantile(rel, 0.999) <= 5e-2
 
 
-@pytest.mark.skipif(os.environ.get("AY_TEST_GRAPH") != "1", reason="HIP-graph replay of a step is not a supported mode (DESIGN.md section 4.1): "
-                    "replays faulted or returned an inconsistent step; set AY_TEST_GRAPH=1 (and AY_DYNAMIC=0) to run it")
 def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):
     """One detection step (native plan forward + decode + merge-NMS) captured as a HIP graph (torch.cuda.CUDAGraph on a side
     stream), replayed after interleaved eager steps on other inputs: same bytes as the eager step on the same input.
 
-    Status: NOT a supported mode (DESIGN.md section 4.1 holds the record).  With the default dynamic item dealing this test
-    ended in a GPU memory access fault in 3 of 4 runs (the runtime's message only shows with pytest's capture off: -s); with
-    AY_DYNAMIC=0 it never faulted but 2 of 4 runs returned an inconsistent step for one replay, also with a device
-    synchronisation in front of the replay (AY_TEST_GRAPH_SYNC=1); with AMD_SERIALIZE_KERNEL=3, and as a plain script
-    (scripts/dbg/graph_testbody.py), every replay matched.  Consecutive kernel nodes of the replayed chain do not behave like
-    stream-ordered launches, which the persistent kernels rely on (counter sets handed back by the last workgroup, arena blocks
-    re-used once their last reader is issued).  A graph buys nothing here anyway (batch-1 latency 3.46 ms eager and replayed), so
-    the mode stays off and this test is opt-in."""
+    The replay is fenced with `utils.graph_replay` (an event recorded behind the replay, waited for by the same stream).  That
+    fence is the root cause found in round 2: on this ROCm 7.2 / PyTorch 2.10 build, work launched into a
+    stream after `hipGraphLaunch` -- and `hipStreamSynchronize` / `hipDeviceSynchronize` -- do NOT wait for the graph's last node,
+    an event recorded on the stream does.  Unfenced, the next eager step overlapped the tail of the replay: 9 of 10 runs returned
+    an inconsistent step (static item dealing) or ended in a GPU memory fault (dynamic dealing: two launches alive on the same
+    arena and counter sets); fenced, 12 of 12 runs matched (3 with static, 9 with dynamic dealing).  AY_TEST_GRAPH_WAIT selects the other waits that
+    were compared (devsync / streamsync fail, tolist / event / waitevent pass) -- only for diagnosis, with AY_DYNAMIC=0."""
     from amyloid_yolo_paper_amd.utils import nms_device
     dev = torch.device("cuda", 0)
     m, _ = build_models(3, tmp_cfg_dir, dev, "bf16")
@@ -107,13 +104,29 @@ def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):
         eager = snapshot(step(xs[2 - k if k != 1 else 1]))   # eager steps in between (they rotate the same counter sets and buffers)
         del eager
         static_x.copy_(xs[k])
-        if os.environ.get("AY_TEST_GRAPH_SYNC") == "1":   # diagnosis: does the replay overlap the eager work queued before it?
+        wait = os.environ.get("AY_TEST_GRAPH_WAIT", "fence")
+        if wait == "fence":
+            ay.graph_replay(g)                  # replay + event fence, no host wait
+        else:
+            g.replay()
+        if wait in ("devsync", "both"):
             torch.cuda.synchronize()
-        g.replay()
-        torch.cuda.synchronize()
+        if wait in ("tolist", "both"):
+            res[2].tolist()                     # blocking device-to-host copy on the launch stream
+        if wait == "streamsync":
+            torch.cuda.current_stream().synchronize()
+        if wait == "event":
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+        if wait == "waitevent":                 # no host wait at all: an event recorded behind the replay, waited for by the same stream
+            ev = torch.cuda.Event()
+            ev.record()
+            torch.cuda.current_stream().wait_event(ev)
         rows, keep, count, cand = res
         rrows, rkeep, rcount, rcand = ref[k]
-        print(f"replay on input {k}: count {count.tolist()} cand {cand.tolist()}; eager {rcount.tolist()} {rcand.tolist()}; all refs {[r[2].tolist() for r in ref]}")
+        if os.environ.get("AY_TEST_GRAPH_PRINT") == "1":
+            print(f"replay on input {k}: count {count.tolist()} cand {cand.tolist()}; eager {rcount.tolist()} {rcand.tolist()}; all refs {[r[2].tolist() for r in ref]}")
         assert torch.equal(count, rcount) and torch.equal(cand, rcand), f"replay on input {k}: counts differ from the eager step"
         for b in range(B):
             n = int(rcount[b])     # rows beyond an image's own count are leftovers of earlier calls
