@@ -27,3 +27,22 @@ for i in range(N):
     model.forward_device(x, out_slot=i & 1)
 torch.cuda.synchronize()
 print("forward only: %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
+
+# the same forward captured as a HIP graph and replayed through the event fence (utils.graph_replay)
+from amyloid_yolo_paper_amd.utils import graph_replay
+side = torch.cuda.Stream(device=dev)
+side.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=side):
+    model.forward_device(x, out_slot=0)
+torch.cuda.synchronize()
+for _ in range(3):
+    graph_replay(g)
+ev = graph_replay(g)
+ev.synchronize()
+t0 = time.perf_counter()
+for i in range(N):
+    ev = graph_replay(g)
+ev.synchronize()
+torch.cuda.synchronize()
+print("forward only, graph replay: %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
