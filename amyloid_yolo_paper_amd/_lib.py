@@ -69,7 +69,7 @@ _SIGS = {
     "ay_yolo_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _F, _F, _P, _P, _P, _SZ, _P]),
     "ay_conv1x1_cat_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P, _P, _P, _P]),
     "ay_resblock_supported": (_I, [_I]),
-    "ay_plan_create": (_I, [C.POINTER(PlanOp), _I, C.POINTER(C.c_size_t), _I, _I, _I, C.POINTER(C.c_void_p)]),
+    "ay_plan_create": (_I, [C.POINTER(PlanOp), _I, C.POINTER(C.c_size_t), _I, _I, _I, _I, C.POINTER(C.c_void_p)]),
     "ay_plan_destroy": (None, [_P]),
     "ay_plan_workspace_bytes": (_SZ, [_P]),
     "ay_plan_value_offset": (_SZ, [_P, _I]),
@@ -107,6 +107,16 @@ _SIGS = {
     "ay_conv_wgrad_bf16_acc": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     "ay_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ay_conv_wgrad_bf16_ws": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, C.c_size_t, _P]),
+    # IEEE-half twins of the inference entry points (same signatures)
+    "ay_pack_conv_weights_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_stem_conv_fwd_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_stem_s2_fused_fwd_f16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "ay_conv_fwd_f16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ay_conv3x3_m16_fwd_f16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ay_conv1x1_cat_fwd_f16": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P, _P, _P, _P]),
+    "ay_resblock_fwd_f16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ay_blocked_f16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_nchw_f32_to_blocked_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

@@ -59,6 +59,39 @@ __device__ __forceinline__ f32x2 leaky2(f32x2 x, float slope) {
     return f32x2{__builtin_fmaxf(x[0], y[0]), __builtin_fmaxf(x[1], y[1])};
 }
 
+// ---- the two 16-bit storage types of the MFMA inference path -------------------------------------------------------
+// The convolution kernels are templates over DT: operand / activation element type, its two matrix instructions and the
+// conversions of the fused epilogue.  Same layouts, same bytes, same MFMA rate; Bf16 keeps fp32's exponent range (training
+// and default), F16 (IEEE binary16, inference only) has an 11-bit significand: an 8x smaller rounding step per stored
+// activation, finite up to 65504 -- stored activations are post-BatchNorm, the fp32 epilogue applies scale / shift before
+// the single rounding.  v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 both round to nearest even.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+struct Bf16 {
+    typedef bf16x8 vec8;
+    static constexpr int id = AY_DT_BF16;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint32_t pack2(f32x2 v) { return pack2bf2(v); }
+    static __device__ __forceinline__ f32x2 unpack2(uint32_t u) { return bf2f2(u); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float to_f32(uint16_t u) { return bf2f(u); }
+};
+struct F16 {
+    typedef f16x8 vec8;
+    static constexpr int id = AY_DT_F16;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint32_t pack2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t)); }
+    static __device__ __forceinline__ f32x2 unpack2(uint32_t u) { return __builtin_convertvector(__builtin_bit_cast(f16x2_t, u), f32x2); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+};
+template <typename DT>
+__device__ __forceinline__ uint32_t pack2_scalar(float lo, float hi) {
+    return (uint32_t)DT::from_f32(lo) | ((uint32_t)DT::from_f32(hi) << 16);
+}
+
 // 16-byte LDS-DMA (global_load_lds_dwordx4): lane l copies 16 B from its own `gsrc` to LDS byte address `lds_addr + 16*l`
 // (`lds_addr` wave-uniform).  Issued through inline asm so that hipcc neither counts it nor guards LDS reads against it:
 // with the builtin the compiler inserted `s_waitcnt vmcnt(0)` between a DMA and the next ds_read / MFMA whenever it could

@@ -46,8 +46,9 @@ __device__ unsigned long long g_phase_ticks_m16[8];
 #define AY_CLK(...)
 #endif
 
-template <bool HAS_RES>
+template <bool HAS_RES, typename DT = Bf16>
 __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, int n_items) {
+    typedef typename DT::vec8 vec8;
     constexpr int BN = 128, TH = 16, TW = 32;
     constexpr int IN_W = TW + 2, IN_PIX = (TH + 2) * IN_W;  // 18 x 34 halo tile
     constexpr int IN_PIXP = (IN_PIX + 15) / 16 * 16;          // 624: half-plane stride, a multiple of 16 pixels (banks)
@@ -257,18 +258,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
             rres[t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo, so, 0);
         };
 
-        bf16x8 fa[2][MT], fb[4];
+        vec8 fa[2][MT], fb[4];
         // kind 0..3: pair j of the slot `sl`; kind 4: the straddle step (both slots)
-        auto ld_a = [&](int kind, int sl, int m) __attribute__((always_inline)) -> bf16x8 {
-            if (kind == 4) return *reinterpret_cast<const bf16x8*>(lds + was + m * 256);
-            return *reinterpret_cast<const bf16x8*>(lds + sl * BUF_BYTES + wa + kind * (4 * BN * 16) + m * 256);
+        auto ld_a = [&](int kind, int sl, int m) __attribute__((always_inline)) -> vec8 {
+            if (kind == 4) return *reinterpret_cast<const vec8*>(lds + was + m * 256);
+            return *reinterpret_cast<const vec8*>(lds + sl * BUF_BYTES + wa + kind * (4 * BN * 16) + m * 256);
         };
-        auto ld_b = [&](int kind, int sl, int n) __attribute__((always_inline)) -> bf16x8 {
+        auto ld_b = [&](int kind, int sl, int n) __attribute__((always_inline)) -> vec8 {
             const int tile = ((n >> 1) * IN_W + (n & 1) * 16) * 16;
-            if (kind == 4) return *reinterpret_cast<const bf16x8*>(lds + pbs + tile + (2 * IN_W + 2) * 16);
+            if (kind == 4) return *reinterpret_cast<const vec8*>(lds + pbs + tile + (2 * IN_W + 2) * 16);
             const int ta = 2 * kind;
             const int tap = ((ta / 3) * IN_W + ta % 3) * 16;
-            return *reinterpret_cast<const bf16x8*>(lds + sl * BUF_BYTES + (kind == 1 ? pb32 : pb1) + tile + tap);
+            return *reinterpret_cast<const vec8*>(lds + sl * BUF_BYTES + (kind == 1 ? pb32 : pb1) + tile + tap);
         };
         // one K32-step: 32 MFMAs; behind the MFMAs of pixel tile n its fragment register takes the next step's tile n, the
         // filter fragments of the next step go to the other register set; PREFETCH = false where the next step's slot has not
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
                 __builtin_amdgcn_s_setprio(3);
 #endif
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][m], fb[n & 3], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc[m][n] = DT::mfma16(fa[cur][m], fb[n & 3], acc[m][n]);
 #if AY_M16_PRIO
                 __builtin_amdgcn_s_setprio(2);
 #endif
@@ -405,11 +406,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
                         const u32x4 rv = rres[t];
                         auto s0 = __builtin_amdgcn_permlane16_swap(rv[0], rv[2], false, false);
                         auto s1 = __builtin_amdgcn_permlane16_swap(rv[1], rv[3], false, false);
-                        x01 += bf2f2(s0[0]), x23 += bf2f2(s1[0]);
-                        y01 += bf2f2(s0[1]), y23 += bf2f2(s1[1]);
+                        x01 += DT::unpack2(s0[0]), x23 += DT::unpack2(s1[0]);
+                        y01 += DT::unpack2(s0[1]), y23 += DT::unpack2(s1[1]);
                     }
-                    auto p0 = __builtin_amdgcn_permlane16_swap(pack2bf2(x01), pack2bf2(y01), false, false);
-                    auto p1 = __builtin_amdgcn_permlane16_swap(pack2bf2(x23), pack2bf2(y23), false, false);
+                    auto p0 = __builtin_amdgcn_permlane16_swap(DT::pack2(x01), DT::pack2(y01), false, false);
+                    auto p1 = __builtin_amdgcn_permlane16_swap(DT::pack2(x23), DT::pack2(y23), false, false);
                     const u32x4 v = u32x4{p0[0], p1[0], p0[1], p1[1]};
                     if constexpr (HAS_RES) {
                         // no store before the last residual load has been consumed (vmcnt retires in order, stores included)
@@ -457,9 +458,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, in
 
 // 3x3 stride-1, cout_pad a multiple of 128, cin a multiple of 32, output rows >= 16: the 16x16x32-MFMA ring kernel.
 // Same arguments and results as ay_conv_fwd_bf16 for those shapes (which calls it); returns AY_ERR_ARG for any other shape.
-extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
-                                       const void* residual, void* out, ay_stream_t stream) {
-    using namespace ay;
+namespace ay {
+template <typename DT>
+static int conv3x3_m16_fwd(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                           const void* residual, void* out, ay_stream_t stream) {
     AY_CHECK_ARG(d && src && w_packed && scale && shift && out, "ay_conv3x3_m16_fwd_bf16: null argument");
     AY_CHECK_ARG(d->ksize == 3 && d->stride == 1 && !d->out_f32 && d->cin % 32 == 0 && d->cout_pad % 128 == 0 && d->cout_pad >= d->cout,
                  "ay_conv3x3_m16_fwd_bf16: shape %dx%d k%d s%d", d->cin, d->cout_pad, d->ksize, d->stride);
@@ -505,9 +507,9 @@ extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, c
     const int cu_slots = conv_num_cus() / 8;
     dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     if (residual)
-        hipLaunchKernelGGL((conv3x3_m16_ring_kernel<true>), pgrid, dim3(512), 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv3x3_m16_ring_kernel<true, DT>), pgrid, dim3(512), 0, st, a, (int)nblk);
     else
-        hipLaunchKernelGGL((conv3x3_m16_ring_kernel<false>), pgrid, dim3(512), 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv3x3_m16_ring_kernel<false, DT>), pgrid, dim3(512), 0, st, a, (int)nblk);
     AY_CHECK_LAUNCH("conv3x3_m16_ring_kernel");
 #ifdef AY_PHASE_CLOCK
     if (a.dbg & 8) {  // timing experiments only: synchronous phase report per launch
@@ -523,4 +525,14 @@ extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, c
     }
 #endif
     return AY_OK;
+}
+}  // namespace ay
+
+extern "C" int ay_conv3x3_m16_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                                       const void* residual, void* out, ay_stream_t stream) {
+    return ay::conv3x3_m16_fwd<ay::Bf16>(d, src, w_packed, scale, shift, residual, out, stream);
+}
+extern "C" int ay_conv3x3_m16_fwd_f16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                                      const void* residual, void* out, ay_stream_t stream) {
+    return ay::conv3x3_m16_fwd<ay::F16>(d, src, w_packed, scale, shift, residual, out, stream);
 }

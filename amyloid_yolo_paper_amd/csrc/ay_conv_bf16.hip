@@ -25,8 +25,9 @@
 
 namespace ay {
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES, typename DT = Bf16>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
+    typedef typename DT::vec8 vec8;
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
     constexpr int NPIX = TH * TW;
@@ -159,18 +160,18 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
             for (int tap = 0; tap < KK2; ++tap) {
                 const int kh = tap / KS, kw = tap % KS;
-                bf16x8 af[MT], bfr[NT];
+                vec8 af[MT], bfr[NT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    af[m] = *reinterpret_cast<const bf16x8*>(lds + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+                    af[m] = *reinterpret_cast<const vec8*>(lds + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    bfr[n] = *reinterpret_cast<const bf16x8*>(lds + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+                    bfr[n] = *reinterpret_cast<const vec8*>(lds + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = DT::mfma32(af[m], bfr[n], acc[m][n]);
             }
         }
         if (more) {
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
 
     ResRegs<MT, NT> rr;
     residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
-    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES, false, 0, false, false, DT>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -201,8 +202,10 @@ __device__ unsigned long long g_phase_ticks[8];
 constexpr int DEAL_SETS = 64, DEAL_STREAMS = 16;
 __device__ unsigned g_deal[DEAL_STREAMS * DEAL_SETS][16];
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false,
+          typename DT = Bf16>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
+    typedef typename DT::vec8 vec8;
     static_assert(!CANVAS || !CAT, "canvas tiling: single-source layers");
     // KS == 2: a 2x2 window with offsets {0, +1} (no padding on the low side) whose channel-group index carries an output pixel
     // parity class; see ConvArgs::w_class_stride
@@ -482,16 +485,16 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
 
             const uint8_t* L = lds + cur * BUF_BYTES;
             constexpr int NSTEP = NK * KK2;
-            bf16x8 af[2][MT], bfr[2][NT];
-            auto load_frags = [&](int t, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) __attribute__((always_inline)) {
+            vec8 af[2][MT], bfr[2][NT];
+            auto load_frags = [&](int t, vec8 (&fa)[MT], vec8 (&fb)[NT]) __attribute__((always_inline)) {
                 const int kk = t / KK2, tap = t % KK2;
                 const int kh = tap / KS, kw = tap % KS;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    fa[m] = *reinterpret_cast<const bf16x8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
+                    fa[m] = *reinterpret_cast<const vec8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    fb[n] = *reinterpret_cast<const bf16x8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+                    fb[n] = *reinterpret_cast<const vec8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
             };
             if (!AY_DBGBIT(a, 2)) load_frags(0, af[0], bfr[0]);
 #pragma unroll
@@ -505,7 +508,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = DT::mfma32(af[t & 1][m], bfr[t & 1][n], acc[m][n]);
                 __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (issued) {
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         }
         int fetched = last;
         if (MAILBOX && tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS, UP2>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS, UP2, DT>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                             reinterpret_cast<const float*>(lds + SS_BASE + par * SSR), cls);
         if (MAILBOX && tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
@@ -680,7 +683,7 @@ static void fill_args(ConvArgs& a, const ay_conv_desc* d, const void* src, const
 
 // RING = false: the 4-wave register-staged kernel (fp32-output heads, cout_pad not a multiple of 64); RING = true: the persistent
 // all-DMA ring kernel
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool RING = false>
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool RING = false, typename DT = Bf16>
 static int launch(const ay_conv_desc* d, const void* src, const void* w, const float* scale, const float* shift,
                   const void* residual, void* out, hipStream_t st) {
     ConvArgs a;
@@ -714,22 +717,22 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
         dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots))), block(512);
         constexpr int NBUF = ring_depth<KS, STRIDE, BN, TH, TW, NK>();
         if (a.canvas_gx && residual)
-            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, true>), pgrid, block, 0, st, a, (int)nblk);
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, true, DT>), pgrid, block, 0, st, a, (int)nblk);
         else if (a.canvas_gx)
-            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, true>), pgrid, block, 0, st, a, (int)nblk);
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, true, DT>), pgrid, block, 0, st, a, (int)nblk);
         else if (residual)
-            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, true, false, false, DT>), pgrid, block, 0, st, a, (int)nblk);
         else
-            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
+            hipLaunchKernelGGL((conv_bf16_ring_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, NBUF, false, false, false, DT>), pgrid, block, 0, st, a, (int)nblk);
     } else {
         dim3 grid((unsigned)nblk), block(256);
         if constexpr (OUT_F32) {
-            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false, DT>), grid, block, 0, st, a);
         } else {
             if (residual)
-                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true>), grid, block, 0, st, a);
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true, DT>), grid, block, 0, st, a);
             else
-                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false>), grid, block, 0, st, a);
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false, DT>), grid, block, 0, st, a);
         }
     }
     AY_CHECK_LAUNCH("conv_bf16_kernel");
@@ -752,7 +755,7 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
 // 1x1 ring kernel launched directly (no residual): CAT = over the route [nearest-x2-upsampled src1 | src2]
 // (models.py:86-96,244-245) without materialising it; BN = 256 = all of a 256-channel group per workgroup (twice the MFMAs per
 // stage barrier of the 128-channel tile, input pixels read once per 256 instead of per 128 output channels)
-template <int BN, int WM, int WN, bool CAT>
+template <int BN, int WM, int WN, bool CAT, typename DT = Bf16>
 static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const void* src2, const void* w, const float* scale,
                           const float* shift, void* out, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NK = 4;
@@ -779,9 +782,9 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
     dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     constexpr int NBUF = ring_depth<1, 1, BN, TH, TW, NK>();
     if (a.canvas_gx)
-        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, false, !CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, false, !CAT, DT>), pgrid, dim3(512), 0, st, a, (int)nblk);
     else
-        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, CAT>), pgrid, dim3(512), 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<1, 1, BN, WM, WN, TH, TW, NK, NBUF, false, CAT, false, DT>), pgrid, dim3(512), 0, st, a, (int)nblk);
     AY_CHECK_LAUNCH("conv_bf16_ring_kernel<1x1>");
     return AY_OK;
 }
@@ -823,16 +826,27 @@ static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w,
 
 }  // namespace ay
 
-extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
-                                       const float* scale, const float* shift, void* out, ay_stream_t stream) {
-    using namespace ay;
+namespace ay {
+template <typename DT>
+static int conv1x1_cat_fwd(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                           const float* scale, const float* shift, void* out, ay_stream_t stream) {
     AY_CHECK_ARG(d && src1_halfres && src2 && w_packed && scale && shift && out, "ay_conv1x1_cat_fwd_bf16: null argument");
     AY_CHECK_ARG(d->ksize == 1 && d->stride == 1 && !d->out_f32, "ay_conv1x1_cat_fwd_bf16: 1x1 stride-1 bf16 only");
     AY_CHECK_ARG(c1 > 0 && c1 % 64 == 0 && d->cin > c1 && (d->cin - c1) % 64 == 0, "ay_conv1x1_cat_fwd_bf16: channel split %d + %d",
                  c1, d->cin - c1);
     AY_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->cout, "ay_conv1x1_cat_fwd_bf16: cout_pad %d (multiple of 128)", d->cout_pad);
     AY_CHECK_ARG(d->hin % 2 == 0 && d->win % 2 == 0 && d->hout == d->hin && d->wout == d->win, "ay_conv1x1_cat_fwd_bf16: even sizes");
-    return launch_ring1x1<128, 2, 4, true>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
+    return launch_ring1x1<128, 2, 4, true, DT>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, S(stream));
+}
+}  // namespace ay
+
+extern "C" int ay_conv1x1_cat_fwd_bf16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                                       const float* scale, const float* shift, void* out, ay_stream_t stream) {
+    return ay::conv1x1_cat_fwd<ay::Bf16>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, stream);
+}
+extern "C" int ay_conv1x1_cat_fwd_f16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                                      const float* scale, const float* shift, void* out, ay_stream_t stream) {
+    return ay::conv1x1_cat_fwd<ay::F16>(d, src1_halfres, c1, src2, w_packed, scale, shift, out, stream);
 }
 
 extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, const void* w_s2_packed, const float* ones, const float* zeros,
@@ -852,9 +866,10 @@ extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, cons
     return launch_dgrad_s2<32, 1, 8, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
 }
 
-extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
-                                const float* shift, const void* residual, void* out, ay_stream_t stream) {
-    using namespace ay;
+namespace ay {
+template <typename DT>
+static int conv_fwd_16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                       const float* shift, const void* residual, void* out, ay_stream_t stream) {
     AY_CHECK_ARG(d && src && w_packed && scale && shift && out, "ay_conv_fwd_bf16: null argument");
     AY_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "ay_conv_fwd_bf16: ksize %d unsupported", d->ksize);
     AY_CHECK_ARG(d->stride == 1 || (d->stride == 2 && d->ksize == 3), "ay_conv_fwd_bf16: stride %d unsupported", d->stride);
@@ -875,34 +890,45 @@ extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const vo
         static const int m16 = getenv("AY_M16") ? atoi(getenv("AY_M16")) : 1;
         int ctx = 0, cty = 0;
         if (cp % 128 == 0 && tile16 && m16 && d->hout >= 16 && d->cin % 32 == 0 && canvas_plan(d, 16, 32, &ctx, &cty) == 0)
-            return ay_conv3x3_m16_fwd_bf16(d, src, w_packed, scale, shift, residual, out, stream);  // v_mfma_f32_16x16x32_bf16
+            return DT::id == AY_DT_F16 ? ay_conv3x3_m16_fwd_f16(d, src, w_packed, scale, shift, residual, out, stream)
+                                       : ay_conv3x3_m16_fwd_bf16(d, src, w_packed, scale, shift, residual, out, stream);  // v_mfma_f32_16x16x32_{bf16,f16}
         if (cp % 128 == 0 && tile16 && d->hout >= 16)
-            return launch<3, 1, 128, 2, 4, 16, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 128 == 0) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+            return launch<3, 1, 128, 2, 4, 16, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 128 == 0) return launch<3, 1, 128, 2, 4, 8, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 1, 64, 1, 8, 8, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
         // 32 output channels (the stem and the data gradients that end in it during training: HBM-bound, 1.4 ms per launch at
         // B=32 / 1024^2 on the register-staged kernel): the ring kernel with a 32-channel tile, one 32x32 block per wave
-        return launch<3, 1, 32, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<3, 1, 32, 1, 8, 8, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
     }
     if (d->ksize == 3 && d->stride == 2) {
         AY_CHECK_ARG(!d->out_f32, "ay_conv_fwd_bf16: 3x3 f32 output unsupported");
-        if (cp % 128 == 0) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        return launch<3, 2, 32, 1, 4, 4, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 128 == 0) return launch<3, 2, 128, 2, 4, 8, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<3, 2, 64, 1, 8, 8, 32, 1, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<3, 2, 32, 1, 4, 4, 32, 1, false, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
     }
     // 1x1
     if (d->cin % 64 == 0) {
         if (d->out_f32) {
-            if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
-            return launch<1, 1, 32, 1, 4, 8, 32, 4, true>(d, src, w_packed, scale, shift, residual, out, st);
+            if (cp % 64 == 0) return launch<1, 1, 64, 1, 4, 8, 32, 4, true, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
+            return launch<1, 1, 32, 1, 4, 8, 32, 4, true, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
         }
         static const int bn256 = getenv("AY_BN256") ? atoi(getenv("AY_BN256")) : 1;
         if (cp % 256 == 0 && !residual && bn256)
-            return launch_ring1x1<256, 4, 2, false>(d, nullptr, 0, src, w_packed, scale, shift, out, st);
-        if (cp % 128 == 0) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        if (cp % 64 == 0) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
-        return launch<1, 1, 32, 1, 8, 8, 32, 4, false, true>(d, src, w_packed, scale, shift, residual, out, st);
+            return launch_ring1x1<256, 4, 2, false, DT>(d, nullptr, 0, src, w_packed, scale, shift, out, st);
+        if (cp % 128 == 0) return launch<1, 1, 128, 2, 4, 8, 32, 4, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        if (cp % 64 == 0) return launch<1, 1, 64, 1, 8, 8, 32, 4, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
+        return launch<1, 1, 32, 1, 8, 8, 32, 4, false, true, DT>(d, src, w_packed, scale, shift, residual, out, st);
     }
-    if (d->out_f32) return launch<1, 1, 32, 1, 4, 8, 32, 1, true>(d, src, w_packed, scale, shift, residual, out, st);
-    return launch<1, 1, 32, 1, 4, 8, 32, 1, false>(d, src, w_packed, scale, shift, residual, out, st);
+    if (d->out_f32) return launch<1, 1, 32, 1, 4, 8, 32, 1, true, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
+    return launch<1, 1, 32, 1, 4, 8, 32, 1, false, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
+}
+}  // namespace ay
+
+extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                                const float* shift, const void* residual, void* out, ay_stream_t stream) {
+    return ay::conv_fwd_16<ay::Bf16>(d, src, w_packed, scale, shift, residual, out, stream);
+}
+extern "C" int ay_conv_fwd_f16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                               const float* shift, const void* residual, void* out, ay_stream_t stream) {
+    return ay::conv_fwd_16<ay::F16>(d, src, w_packed, scale, shift, residual, out, stream);
 }

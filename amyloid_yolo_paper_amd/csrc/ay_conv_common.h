@@ -125,7 +125,7 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 // CANVAS: the tile lies on the canvas of ConvArgs::canvas_gx (a compile-time switch: as run-time branches the mapping code
 // cost the kernels that never use it SGPR spills -- the fused block went from 1.36 to 1.81 ms)
 template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0, bool CANVAS = false,
-          bool UP2 = false>
+          bool UP2 = false, typename DT = Bf16>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
                                               int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr, int cls = 0) {
     static_assert(!UP2 || (!CANVAS && !OUT_F32), "parity-class output: plain bf16 tiles");
@@ -247,10 +247,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                             rv = rr.r[m][n][qp];
                         auto sx = __builtin_amdgcn_permlane32_swap(rv.x, rv.z, false, false);
                         auto sy = __builtin_amdgcn_permlane32_swap(rv.y, rv.w, false, false);
-                        v01 += bf2f2(sx[0]), v23 += bf2f2(sy[0]);
-                        w01 += bf2f2(sx[1]), w23 += bf2f2(sy[1]);
+                        v01 += DT::unpack2(sx[0]), v23 += DT::unpack2(sy[0]);
+                        w01 += DT::unpack2(sx[1]), w23 += DT::unpack2(sy[1]);
                     }
-                    const unsigned ax = pack2bf2(v01), ay_ = pack2bf2(v23), bx = pack2bf2(w01), by = pack2bf2(w23);
+                    const unsigned ax = DT::pack2(v01), ay_ = DT::pack2(v23), bx = DT::pack2(w01), by = DT::pack2(w23);
                     auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(ay_, by, false, false);
                     // plain stores: `nt` (streaming) stores were measured slower -- their completion, which the next stage's

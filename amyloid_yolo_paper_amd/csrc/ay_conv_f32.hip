@@ -1,6 +1,7 @@
 // fp32 parity path: the same convolutional block in the reference's own layout (nchw f32, OIHW f32
-// weights), plain fp32 FMA accumulation.  Used where results must match the reference's fp32 CPU path
-// to 1e-4 (tests, precision="fp32" mode of the Darknet host class); not the throughput path.
+// weights), fp32 accumulation.  Used where results must match the reference's fp32 CPU path
+// to 1e-4 (tests, precision="fp32" mode of the Darknet host class).  The cfg format's shapes (1x1 / 3x3, stride 1 / 2) run on
+// the exact-fp32 MFMA kernel of ay_conv_f32_mfma.hip; the VALU kernel below serves any other shape and AY_F32_MFMA=0.
 // Route concat + nearest x2 upsample (models.py:86-96,244-245) are folded into the loader.
 #include "ay_common.h"
 
@@ -66,6 +67,9 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__
     }
 }
 
+int conv_fwd_f32_mfma(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2, const float* w, const float* scale,
+                      const float* shift, const float* residual, float* out, hipStream_t st, bool* taken);  // ay_conv_f32_mfma.hip
+
 }  // namespace ay
 
 extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
@@ -78,6 +82,9 @@ extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin
     const int pad = (d->ksize - 1) / 2;
     AY_CHECK_ARG(d->hout == (d->hin + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (d->win + 2 * pad - d->ksize) / d->stride + 1,
                  "ay_conv_fwd_f32: output size mismatch");
+    bool taken = false;
+    const int rc = conv_fwd_f32_mfma(d, src1, cin1, up1, src2, w_oihw, scale, shift, residual, out, S(stream), &taken);
+    if (taken) return rc;
     const int cgroups = (d->cout + CO_T - 1) / CO_T;
     const long long gz = (long long)d->batch * cgroups;
     AY_CHECK_ARG(gz <= 65535, "ay_conv_fwd_f32: batch*cout/4 = %lld exceeds grid.z", gz);

@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 
 // OIHW f32 -> [cin/16][tap][half][cout_pad][8] bf16
+template <typename DT>
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cout_pad,
                                     int cin, int ks) {
     const int kk2 = ks * ks;
@@ -30,7 +31,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
         const int ci = chunk * 16 + half * 8 + j;
         float v = 0.f;
         if (co < cout) v = w[((size_t)co * cin + ci) * kk2 + tap];
-        out[i] = f2bf(v);
+        out[i] = DT::from_f32(v);
     }
 }
 
@@ -54,6 +55,7 @@ __global__ void fold_bn_kernel(const float* gamma, const float* beta, const floa
 
 // Stem (models.py layer 0): nchw f32 [B,3,H,W] -> blocked bf16 [B][2][H][W][16], 3x3 s1 pad 1, fp32 math.
 // One thread = one output pixel x 32 channels; filters are wave-uniform (scalar loads).
+template <typename DT>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         uint8_t* __restrict__ out, int H, int W, int leaky) {
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
             if (leaky) s = s > 0.f ? s : 0.1f * s;
             acc[j] = s;
         }
-        uint4 o = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+        uint4 o = make_uint4(pack2_scalar<DT>(acc[0], acc[1]), pack2_scalar<DT>(acc[2], acc[3]), pack2_scalar<DT>(acc[4], acc[5]), pack2_scalar<DT>(acc[6], acc[7]));
         const size_t pl = (size_t)b * 2 + (half >> 1);
         *reinterpret_cast<uint4*>(out + (pl * plane + pix) * 32 + (half & 1) * 16) = o;
     }
@@ -121,7 +123,7 @@ __global__ void concat_upsample_kernel(const uint8_t* __restrict__ s1, int p1, i
     }
 }
 
-template <typename T>
+template <typename T, typename DT = Bf16>
 __global__ void blocked_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W) {
     const size_t total = (size_t)B * C * H * W;
     const int CP = (C + 15) / 16;
@@ -134,12 +136,13 @@ __global__ void blocked_to_nchw_kernel(const T* __restrict__ src, float* __restr
         const int b = (int)(t / C);
         const size_t s = ((((size_t)b * CP + (ch >> 4)) * H + y) * W + x) * 16 + (ch & 15);
         if constexpr (sizeof(T) == 2)
-            dst[i] = bf2f(src[s]);
+            dst[i] = DT::to_f32(src[s]);
         else
             dst[i] = src[s];
     }
 }
 
+template <typename DT>
 __global__ void nchw_to_blocked_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int B, int C, int H,
                                             int W) {
     const int CP = (C + 15) / 16;
@@ -156,7 +159,7 @@ __global__ void nchw_to_blocked_bf16_kernel(const float* __restrict__ src, uint1
         const int ch = pl * 16 + j;
         float v = 0.f;
         if (ch < C) v = src[(((size_t)b * C + ch) * H + y) * W + x];
-        dst[i] = f2bf(v);
+        dst[i] = DT::from_f32(v);
     }
 }
 
@@ -178,14 +181,22 @@ extern "C" size_t ay_packed_weight_bytes(int cout_pad, int cin, int ksize) {
     return (size_t)(cin / 16) * ksize * ksize * 2 * cout_pad * 8 * 2;
 }
 
-extern "C" int ay_pack_conv_weights_bf16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize,
-                                         ay_stream_t stream) {
-    AY_CHECK_ARG(w_oihw && packed && cin % 16 == 0 && cout_pad >= cout && cout_pad % 16 == 0, "ay_pack_conv_weights_bf16: bad args");
+template <typename DT>
+static int pack_conv_weights(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize, ay_stream_t stream) {
+    AY_CHECK_ARG(w_oihw && packed && cin % 16 == 0 && cout_pad >= cout && cout_pad % 16 == 0, "ay_pack_conv_weights: bad args");
     const size_t total = ay_packed_weight_bytes(cout_pad, cin, ksize) / 2;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S(stream), w_oihw, (uint16_t*)packed, cout,
+    hipLaunchKernelGGL(pack_weights_kernel<DT>, dim3(grid_for(total, 256)), dim3(256), 0, S(stream), w_oihw, (uint16_t*)packed, cout,
                        cout_pad, cin, ksize);
     AY_CHECK_LAUNCH("pack_weights_kernel");
     return AY_OK;
+}
+extern "C" int ay_pack_conv_weights_bf16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize,
+                                         ay_stream_t stream) {
+    return pack_conv_weights<Bf16>(w_oihw, packed, cout, cout_pad, cin, ksize, stream);
+}
+extern "C" int ay_pack_conv_weights_f16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize,
+                                        ay_stream_t stream) {
+    return pack_conv_weights<F16>(w_oihw, packed, cout, cout_pad, cin, ksize, stream);
 }
 
 extern "C" int ay_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
@@ -198,15 +209,24 @@ extern "C" int ay_fold_bn(const float* gamma, const float* beta, const float* me
     return AY_OK;
 }
 
-extern "C" int ay_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
-                                void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream) {
+template <typename DT>
+static int stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                         void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream) {
     AY_CHECK_ARG(x_nchw && w_oihw && scale && shift && out_blocked && batch > 0 && h > 0 && w > 0, "ay_stem_conv_fwd: bad args");
     AY_CHECK_ARG(batch <= 65535, "ay_stem_conv_fwd: batch too large");
     dim3 grid((w + 63) / 64, (h + 3) / 4, batch);
-    hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), 0, S(stream), x_nchw, w_oihw, scale, shift, (uint8_t*)out_blocked, h, w,
+    hipLaunchKernelGGL(stem_conv_kernel<DT>, grid, dim3(256), 0, S(stream), x_nchw, w_oihw, scale, shift, (uint8_t*)out_blocked, h, w,
                        leaky);
     AY_CHECK_LAUNCH("stem_conv_kernel");
     return AY_OK;
+}
+extern "C" int ay_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                                void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream) {
+    return stem_conv_fwd<Bf16>(x_nchw, w_oihw, scale, shift, out_blocked, batch, h, w, leaky, stream);
+}
+extern "C" int ay_stem_conv_fwd_f16(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                                    void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream) {
+    return stem_conv_fwd<F16>(x_nchw, w_oihw, scale, shift, out_blocked, batch, h, w, leaky, stream);
 }
 
 extern "C" int ay_concat_upsample_bf16(const void* src1, int c1, int up1, const void* src2, int c2, void* out, int batch, int h,
@@ -229,6 +249,15 @@ extern "C" int ay_blocked_bf16_to_nchw_f32(const void* src, float* dst, int batc
     return AY_OK;
 }
 
+extern "C" int ay_blocked_f16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(src && dst, "ay_blocked_f16_to_nchw_f32: null");
+    const size_t n = (size_t)batch * c * h * w;
+    hipLaunchKernelGGL((blocked_to_nchw_kernel<uint16_t, F16>), dim3(grid_for(n, 256)), dim3(256), 0, S(stream), (const uint16_t*)src, dst,
+                       batch, c, h, w);
+    AY_CHECK_LAUNCH("blocked_to_nchw_kernel");
+    return AY_OK;
+}
+
 extern "C" int ay_blocked_f32_to_nchw_f32(const float* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(src && dst, "ay_blocked_f32_to_nchw_f32: null");
     const size_t n = (size_t)batch * c * h * w;
@@ -240,8 +269,17 @@ extern "C" int ay_blocked_f32_to_nchw_f32(const float* src, float* dst, int batc
 extern "C" int ay_nchw_f32_to_blocked_bf16(const float* src, void* dst, int batch, int c, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(src && dst, "ay_nchw_f32_to_blocked_bf16: null");
     const size_t n = (size_t)batch * ((c + 15) / 16) * h * w * 16;
-    hipLaunchKernelGGL(nchw_to_blocked_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), src, (uint16_t*)dst, batch, c, h,
+    hipLaunchKernelGGL(nchw_to_blocked_bf16_kernel<Bf16>, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), src, (uint16_t*)dst, batch, c, h,
                        w);
     AY_CHECK_LAUNCH("nchw_to_blocked_bf16_kernel");
+    return AY_OK;
+}
+
+extern "C" int ay_nchw_f32_to_blocked_f16(const float* src, void* dst, int batch, int c, int h, int w, ay_stream_t stream) {
+    AY_CHECK_ARG(src && dst, "ay_nchw_f32_to_blocked_f16: null");
+    const size_t n = (size_t)batch * ((c + 15) / 16) * h * w * 16;
+    hipLaunchKernelGGL(nchw_to_blocked_bf16_kernel<F16>, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), src, (uint16_t*)dst, batch, c, h,
+                       w);
+    AY_CHECK_LAUNCH("nchw_to_blocked_f16_kernel");
     return AY_OK;
 }

@@ -19,6 +19,7 @@ struct ay_plan {
     std::vector<int> def_op, last_use;
     size_t arena = 0;
     int img_dim = 0, n_total = 0;
+    int dtype = AY_DT_BF16;  // storage type of activations and packed filters
     // profiling (ay_plan_profile_begin/end): one event list per recorded forward, a pair per selected op
     mutable bool profiling = false;
     mutable std::vector<std::vector<hipEvent_t>> prof_events;
@@ -41,6 +42,25 @@ void op_reads(const ay_plan_op& o, int (&r)[3]) {
 int issue(const ay_plan* p, const ay_plan_op& o, const float* x, uint8_t* ws, float* out, ay_stream_t st) {
     auto at = [&](int v) -> void* { return v >= 0 ? ws + p->offset[v] : nullptr; };
     const ay_conv_desc& d = o.conv;
+    if (p->dtype == AY_DT_F16) {
+        switch (o.kind) {
+            case AY_OP_STEM_S2_FUSED:
+                return ay_stem_s2_fused_fwd_f16(x, o.w, o.scale, o.shift, d.leaky, o.w2, o.scale2, o.shift2, o.leaky2, at(o.dst), d.batch,
+                                                p->img_dim, p->img_dim, st);
+            case AY_OP_STEM:
+                return ay_stem_conv_fwd_f16(x, static_cast<const float*>(o.w), o.scale, o.shift, at(o.dst), d.batch, p->img_dim, p->img_dim,
+                                            d.leaky, st);
+            case AY_OP_CONV:
+                return ay_conv_fwd_f16(&d, at(o.src), o.w, o.scale, o.shift, at(o.res), at(o.dst), st);
+            case AY_OP_RESBLOCK:
+                return ay_resblock_fwd_f16(at(o.src), o.w, o.scale, o.shift, d.leaky, o.w2, o.scale2, o.shift2, o.leaky2, at(o.dst),
+                                           d.batch, d.cin, d.hout, d.wout, st);
+            case AY_OP_CONV1X1_CAT:
+                return ay_conv1x1_cat_fwd_f16(&d, at(o.src), o.c1, at(o.src2), o.w, o.scale, o.shift, at(o.dst), st);
+            default:
+                break;  // 16-bit copies and the fp32 decode: the same entry points
+        }
+    }
     switch (o.kind) {
         case AY_OP_STEM_S2_FUSED:
             return ay_stem_s2_fused_fwd(x, o.w, o.scale, o.shift, d.leaky, o.w2, o.scale2, o.shift2, o.leaky2, at(o.dst), d.batch,
@@ -68,7 +88,8 @@ int issue(const ay_plan* p, const ay_plan_op& o, const float* x, uint8_t* ws, fl
 }  // namespace
 
 extern "C" int ay_plan_create(const ay_plan_op* ops, int n_ops, const size_t* value_bytes, int n_values, int img_dim,
-                              int n_total_rows, ay_plan** out_plan) {
+                              int n_total_rows, int act_dtype, ay_plan** out_plan) {
+    AY_CHECK_ARG(act_dtype == AY_DT_BF16 || act_dtype == AY_DT_F16, "ay_plan_create: activation dtype %d", act_dtype);
     AY_CHECK_ARG(ops && value_bytes && out_plan && n_ops > 0 && n_values > 0, "ay_plan_create: null / empty argument");
     AY_CHECK_ARG(img_dim > 0 && img_dim % 32 == 0 && n_total_rows > 0, "ay_plan_create: image side %d, %d rows", img_dim, n_total_rows);
     ay_plan* p = new ay_plan;
@@ -79,6 +100,7 @@ extern "C" int ay_plan_create(const ay_plan_op* ops, int n_ops, const size_t* va
     p->last_use.assign(n_values, -1);
     p->img_dim = img_dim;
     p->n_total = n_total_rows;
+    p->dtype = act_dtype;
     auto fail = [&](const char* what, int op, int v) {
         ay::set_error("ay_plan_create: op %d: %s (value %d)", op, what, v);
         delete p;

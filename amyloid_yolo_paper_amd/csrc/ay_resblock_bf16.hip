@@ -33,8 +33,9 @@ struct ResBlockArgs {
     ConvArgs c2;         // the 3x3 as conv_epilogue sees it (out, residual = x, scale/shift, sizes)
 };
 
-template <int CM, int TH, int NKA, int NBUF>   // mid channels; tile rows; 16-channel chunks of x per phase-A stage; ring depth
+template <int CM, int TH, int NKA, int NBUF, typename DT = Bf16>   // mid channels; tile rows; 16-channel chunks of x per phase-A stage; ring depth; storage type
 __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, int n_items) {
+    typedef typename DT::vec8 vec8;
     constexpr int C = 2 * CM;
     constexpr int TW = 32, IN_W = TW + 2, IN_H = TH + 2;
     constexpr int HP = IN_H * IN_W;                 // halo pixels (340 for 8 rows, 612 for 16)
@@ -214,18 +215,18 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             const uint8_t* L = lds + cur * SLOT;
-            bf16x8 fa[NKA], fb[NKA][NBA];
+            vec8 fa[NKA], fb[NKA][NBA];
 #pragma unroll
             for (int kk = 0; kk < NKA; ++kk) {
-                fa[kk] = *reinterpret_cast<const bf16x8*>(L + kk * XSLAB + wa1);
+                fa[kk] = *reinterpret_cast<const vec8*>(L + kk * XSLAB + wa1);
 #pragma unroll
                 for (int j = 0; j < NBA; ++j)
-                    fb[kk][j] = *reinterpret_cast<const bf16x8*>(L + kk * XSLAB + (hh * HP + (wna + j * WNA) * 32 + c) * 16);
+                    fb[kk][j] = *reinterpret_cast<const vec8*>(L + kk * XSLAB + (hh * HP + (wna + j * WNA) * 32 + c) * 16);
             }
 #pragma unroll
             for (int kk = 0; kk < NKA; ++kk) {
 #pragma unroll
-                for (int j = 0; j < NBA; ++j) accA[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][j], accA[j], 0, 0, 0);
+                for (int j = 0; j < NBA; ++j) accA[j] = DT::mfma32(fa[kk], fb[kk][j], accA[j]);
                 if (issued) {
 #pragma unroll
                     for (int i = 0; i < PW; ++i)
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
                         }
                         // channel wma*32 + 8q + 4hh + e -> chunk wma*2 + (q>>1), half q&1, element 4hh+e
                         uint8_t* dst = lds + OFF_MID + (wma * 2 + (q >> 1)) * MID_SLAB + ((q & 1) * HPP + P) * 16 + hh * 8;
-                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_scalar<DT>(o[0], o[1]), pack2_scalar<DT>(o[2], o[3]));
                     }
                 }
             }
@@ -285,13 +286,13 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             const uint8_t* L = lds + cur * SLOT;
             const uint8_t* M = lds + OFF_MID + kb * MID_SLAB;
-            bf16x8 af[2][MT], bfr[2][NT];
-            auto load_frags = [&](int tap, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) __attribute__((always_inline)) {
+            vec8 af[2][MT], bfr[2][NT];
+            auto load_frags = [&](int tap, vec8 (&fa)[MT], vec8 (&fb)[NT]) __attribute__((always_inline)) {
                 const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(L + wa2 + (tap * 2 * BN2 + m * 32) * 16);
+                for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const vec8*>(L + wa2 + (tap * 2 * BN2 + m * 32) * 16);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(M + pb[n] + (kh * IN_W + kw) * 16);
+                for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const vec8*>(M + pb[n] + (kh * IN_W + kw) * 16);
             };
             load_frags(0, af[0], bfr[0]);
 #pragma unroll
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][m], bfr[t & 1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = DT::mfma32(af[t & 1][m], bfr[t & 1][n], acc[m][n]);
                 __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (issued) {
@@ -316,19 +317,19 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             stage_end(issued, !(last_stage && !has_next));
             if (++cur == NBUF) cur = 0;
         }
-        conv_epilogue<BN2, MT, NT, TW, false, true, true, 2>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN2, MT, NT, TW, false, true, true, 2, false, false, DT>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
                                                             reinterpret_cast<const float*>(lds + OFF_SS2));
         if (!has_next) break;
         item = next_item;
     }
 }
 
-template <int CM, int TH, int NKA, int NBUF>
+template <int CM, int TH, int NKA, int NBUF, typename DT>
 static int launch_resblock(const ResBlockArgs& s, int n_items, hipStream_t st) {
     const int per_xcd = (n_items + 7) / 8;
     const int cu_slots = conv_num_cus() / 8;
     dim3 grid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
-    hipLaunchKernelGGL((resblock_bf16_kernel<CM, TH, NKA, NBUF>), grid, dim3(512), 0, st, s, n_items);
+    hipLaunchKernelGGL((resblock_bf16_kernel<CM, TH, NKA, NBUF, DT>), grid, dim3(512), 0, st, s, n_items);
     AY_CHECK_LAUNCH("resblock_bf16_kernel");
     return AY_OK;
 }
@@ -337,10 +338,11 @@ static int launch_resblock(const ResBlockArgs& s, int n_items, hipStream_t st) {
 
 extern "C" int ay_resblock_supported(int channels) { return channels == 64 || channels == 128; }
 
-extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
-                                    const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
-                                    int channels, int h, int w, ay_stream_t stream) {
-    using namespace ay;
+namespace ay {
+template <typename DT>
+static int resblock_fwd(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
+                        const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
+                        int channels, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(x && w1_packed && scale1 && shift1 && w2_packed && scale2 && shift2 && out, "ay_resblock_fwd_bf16: null");
     AY_CHECK_ARG(ay_resblock_supported(channels), "ay_resblock_fwd_bf16: %d channels unsupported (64 or 128)", channels);
     AY_CHECK_ARG(batch > 0 && h > 0 && w > 0 && x != out, "ay_resblock_fwd_bf16: bad shape / in-place");
@@ -378,5 +380,17 @@ extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const 
     a.c1 = 0;
     const long long n_items = (long long)a.tiles_x * a.tiles_y * batch;
     AY_CHECK_ARG(n_items > 0 && n_items < 0x7fffffffLL, "ay_resblock_fwd_bf16: grid");
-    return channels == 128 ? launch_resblock<64, 8, 2, 3>(s, (int)n_items, S(stream)) : launch_resblock<32, 16, 1, 4>(s, (int)n_items, S(stream));
+    return channels == 128 ? launch_resblock<64, 8, 2, 3, DT>(s, (int)n_items, S(stream)) : launch_resblock<32, 16, 1, 4, DT>(s, (int)n_items, S(stream));
+}
+}  // namespace ay
+
+extern "C" int ay_resblock_fwd_bf16(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
+                                    const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
+                                    int channels, int h, int w, ay_stream_t stream) {
+    return ay::resblock_fwd<ay::Bf16>(x, w1_packed, scale1, shift1, leaky1, w2_packed, scale2, shift2, leaky2, out, batch, channels, h, w, stream);
+}
+extern "C" int ay_resblock_fwd_f16(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
+                                   const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
+                                   int channels, int h, int w, ay_stream_t stream) {
+    return ay::resblock_fwd<ay::F16>(x, w1_packed, scale1, shift1, leaky1, w2_packed, scale2, shift2, leaky2, out, batch, channels, h, w, stream);
 }

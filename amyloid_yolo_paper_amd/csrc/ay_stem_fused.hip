@@ -38,7 +38,9 @@ struct StemFusedArgs {
 };
 
 // 16 waves: every phase is a chain of dependent LDS round trips per wave, so more (shorter) chains per CU, not wider ones
+template <typename DT>
 __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, int n_items) {
+    typedef typename DT::vec8 vec8;
     constexpr int TH = 8, TW = 32, BN = 64;
     constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 17 x 65 stem pixels feed the tile
     constexpr int S_PIX = SH * SW;                        // 1105
@@ -81,9 +83,9 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
     for (int u = tid; u < W1_BYTES / 16; u += NT_)
         *reinterpret_cast<uint4*>(lds + OFF_W1 + u * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.w) + (size_t)u * 16);
     // stem filters as the MFMA A operand: lane (row co = c, half hh), k-step ks: k = 16*ks + 8*hh + j
-    bf16x8 wa[2];
+    vec8 wa[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wa[ks] = *reinterpret_cast<const bf16x8*>(s.w0 + c * 32 + 16 * ks + 8 * hh);
+    for (int ks = 0; ks < 2; ++ks) wa[ks] = *reinterpret_cast<const vec8*>(s.w0 + c * 32 + 16 * ks + 8 * hh);
     asm volatile("" ::"v"(wa[0]), "v"(wa[1]));  // complete these loads here: a wait at their first use inside the loop would be
                                                  // executed every item and drain the tile DMAs with it
 
@@ -182,10 +184,10 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
                     auto idx = [&](int k) { return koff(k) >= 0 ? ibase + koff(k) : IMG_ELEMS; };
                     const int i0 = hh ? idx(16 * ks + 8 + 2 * jj) : idx(16 * ks + 2 * jj);
                     const int i1 = hh ? idx(16 * ks + 8 + 2 * jj + 1) : idx(16 * ks + 2 * jj + 1);
-                    pk[jj] = pack2bf(img[i0], img[i1]);
+                    pk[jj] = pack2_scalar<DT>(img[i0], img[i1]);
                 }
                 const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], __builtin_bit_cast(bf16x8, pv), acc, 0, 0, 0);
+                acc = DT::mfma32(wa[ks], __builtin_bit_cast(vec8, pv), acc);
             }
             // rows = stem channels (reg&3)+8*(reg>>2)+4*hh, col = pixel c.  Outside the image the stem output is layer 1's
             // zero padding, not leaky(shift).
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
                 }
                 // channel 8q+4hh+j -> chunk q>>1, half q&1, element 4hh+j
                 uint8_t* dst = lds + OFF_STEM + (q >> 1) * SLAB + ((q & 1) * S_PIXP + P) * 16 + hh * 8;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_scalar<DT>(o[0], o[1]), pack2_scalar<DT>(o[2], o[3]));
             }
         }
         STEM_TICK(1)
@@ -225,19 +227,19 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
-                bf16x8 af[MT];
+                vec8 af[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    af[m] = *reinterpret_cast<const bf16x8*>(lds + wa1 + ((ch * 9 + tap) * 2 * BN + m * 32) * 16);
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(lds + OFF_STEM + ch * SLAB + pb + (kh * SW + kw) * 16);
+                    af[m] = *reinterpret_cast<const vec8*>(lds + wa1 + ((ch * 9 + tap) * 2 * BN + m * 32) * 16);
+                const vec8 bfr = *reinterpret_cast<const vec8*>(lds + OFF_STEM + ch * SLAB + pb + (kh * SW + kw) * 16);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc1[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc1[m][0], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc1[m][0] = DT::mfma32(af[m], bfr, acc1[m][0]);
             }
         }
         STEM_TICK(3)
         // ---- D: epilogue ----------------------------------------------------------------------------------
         ResRegs<MT, NT> rr;
-        conv_epilogue<BN, MT, NT, TW, false, false, false, 2>(a, acc1, rr, b, 0, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN, MT, NT, TW, false, false, false, 2, false, false, DT>(a, acc1, rr, b, 0, wm, wn, c, hh, y0, x0,
                                                               reinterpret_cast<const float*>(lds + OFF_SS1));
         STEM_TICK(4)
 #ifdef AY_PHASE_CLOCK
@@ -293,7 +295,9 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
 //     1) grid rows: every LDS read of the stem is one per-lane base + an immediate; the 5 spare slots carry zero filters and
 //     re-read taps of the same or the next pixel row (finite whenever the image is).  Producers hold scale / shift in
 //     registers, LeakyReLU is max(t, slope t), two values per convert
+template <typename DT>
 __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s, int n_items) {
+    typedef typename DT::vec8 vec8;
     constexpr int TH = 4, TW = 32, BN = 64;
     constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 9 x 65 stem pixels feed the tile
     constexpr int S_PIX = SH * SW;                        // 585
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
         auto slotC = [](int e) constexpr { return e < 6 ? 18 + e : (e == 6 ? 2 * 3 + 2 : 5 * 3 + 2); };
         auto goff = [](int t) constexpr { return (t / 3) * IW + t % 3; };                       // float offset of grid tap t
         auto kref = [](int t) constexpr { return ((t / 3) % 3) * 9 + (t / 9) * 3 + t % 3; };   // its index ci*9 + kh*3 + kw in w0
-        bf16x8 wa[2];
+        vec8 wa[2];
         {
             const uint16_t* wr = s.w0 + c * 32;   // filters of output channel c
             uint16_t w0v[8], w1v[8];
@@ -412,9 +416,9 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
                 const int td = slotC(e) + 6;      // half 1 of step 1: real only for grid row 8
                 w1v[e] = hh ? (td / 3 == 8 ? wr[kref(td)] : (uint16_t)0) : wr[kref(slotC(e))];
             }
-            wa[0] = __builtin_bit_cast(bf16x8, make_uint4(w0v[0] | (unsigned)w0v[1] << 16, w0v[2] | (unsigned)w0v[3] << 16,
+            wa[0] = __builtin_bit_cast(vec8, make_uint4(w0v[0] | (unsigned)w0v[1] << 16, w0v[2] | (unsigned)w0v[3] << 16,
                                                            w0v[4] | (unsigned)w0v[5] << 16, w0v[6] | (unsigned)w0v[7] << 16));
-            wa[1] = __builtin_bit_cast(bf16x8, make_uint4(w1v[0] | (unsigned)w1v[1] << 16, w1v[2] | (unsigned)w1v[3] << 16,
+            wa[1] = __builtin_bit_cast(vec8, make_uint4(w1v[0] | (unsigned)w1v[1] << 16, w1v[2] | (unsigned)w1v[3] << 16,
                                                            w1v[4] | (unsigned)w1v[5] << 16, w1v[6] | (unsigned)w1v[7] << 16));
         }
         // stem scale / shift of this lane's 16 output channels 8q + 4hh + 2j2 (+1)
@@ -463,13 +467,13 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
                         v0[jj] = f32x2{p0[goff(slotA(2 * jj))], p0[goff(slotA(2 * jj + 1))]};
                         v1[jj] = f32x2{p1[goff(slotC(2 * jj))], p1[goff(slotC(2 * jj + 1))]};
                     }
-                    const uint4 b0 = make_uint4(pack2bf2(v0[0]), pack2bf2(v0[1]), pack2bf2(v0[2]), pack2bf2(v0[3]));
-                    const uint4 b1 = make_uint4(pack2bf2(v1[0]), pack2bf2(v1[1]), pack2bf2(v1[2]), pack2bf2(v1[3]));
+                    const uint4 b0 = make_uint4(DT::pack2(v0[0]), DT::pack2(v0[1]), DT::pack2(v0[2]), DT::pack2(v0[3]));
+                    const uint4 b1 = make_uint4(DT::pack2(v1[0]), DT::pack2(v1[1]), DT::pack2(v1[2]), DT::pack2(v1[3]));
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                    acc = DT::mfma32(wa[0], __builtin_bit_cast(vec8, b0), acc);
+                    acc = DT::mfma32(wa[1], __builtin_bit_cast(vec8, b1), acc);
                     bool real = true;
                     if (!interior) {   // border tile: pixels outside the image are the zero padding of layer 1
                         const int P = (wave + 8 * j) * 32 + c;
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
                     for (int q = 0; q < 4; ++q) {
                         const f32x2 t0 = leaky2(f32x2{acc[4 * q], acc[4 * q + 1]} * sc0[2 * q] + sh0[2 * q], slope0);
                         const f32x2 t1 = leaky2(f32x2{acc[4 * q + 2], acc[4 * q + 3]} * sc0[2 * q + 1] + sh0[2 * q + 1], slope0);
-                        uint2 o = make_uint2(pack2bf2(t0), pack2bf2(t1));
+                        uint2 o = make_uint2(DT::pack2(t0), DT::pack2(t1));
                         if (!real) o = make_uint2(0u, 0u);
                         *reinterpret_cast<uint2*>(dst + (q >> 1) * SLAB + (q & 1) * S_POSP * 16) = o;
                     }
@@ -510,10 +514,10 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
         // layer 1: 8 waves = 2 (32-channel halves) x 4 (output rows); filters [chunk][tap][half][64][8] straight from HBM into registers
         const int cwv = wave & 7;
         const int wn = cwv & 3, wm = cwv >> 2;
-        bf16x8 wf[18];
+        vec8 wf[18];
 #pragma unroll
         for (int n = 0; n < 18; ++n)
-            wf[n] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(n * 2 + hh) * BN + wm * 32 + c) * 16);
+            wf[n] = *reinterpret_cast<const vec8*>(a.w + ((size_t)(n * 2 + hh) * BN + wm * 32 + c) * 16);
         // cell of input pixel (row 2*wn + kh, column 2*c + kw): (2*wn + kh)*ROWP + (kw & 1)*HALFW + c + (kw >> 1)
         const int pb = (hh * S_POSP + (wn * 2) * ROWP + c) * 16;
         Coord cP = cA;   // item k-1
@@ -531,12 +535,12 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
                 f32x16 acc1[MT][NT];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[0][0][r] = 0.f;
-                bf16x8 fb[2][3];   // pixel fragments one filter row ahead of the MFMAs that use them
+                vec8 fb[2][3];   // pixel fragments one filter row ahead of the MFMAs that use them
                 auto load_row = [&](int n, int sl) __attribute__((always_inline)) {
                     const int ch = n / 3, kh = n % 3;
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
-                        fb[sl][kw] = *reinterpret_cast<const bf16x8*>(set + ch * SLAB + pb + (kh * ROWP + (kw & 1) * HALFW + (kw >> 1)) * 16);
+                        fb[sl][kw] = *reinterpret_cast<const vec8*>(set + ch * SLAB + pb + (kh * ROWP + (kw & 1) * HALFW + (kw >> 1)) * 16);
                 };
                 load_row(0, 0);
 #pragma unroll
@@ -545,12 +549,12 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
-                        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n * 3 + kw], fb[n & 1][kw], acc1[0][0], 0, 0, 0);
+                        acc1[0][0] = DT::mfma32(wf[n * 3 + kw], fb[n & 1][kw], acc1[0][0]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 STEM2_TICK(8, 4)
                 ResRegs<MT, NT> rr;
-                conv_epilogue<BN, MT, NT, TW, false, false, false, 2>(a, acc1, rr, cP.b, 0, wm, wn, c, hh, cP.y0, cP.x0,
+                conv_epilogue<BN, MT, NT, TW, false, false, false, 2, false, false, DT>(a, acc1, rr, cP.b, 0, wm, wn, c, hh, cP.y0, cP.x0,
                                                                       reinterpret_cast<const float*>(lds + OFF_SS1));
                 stored = (cP.y0 + wn) < a.hout;
             }
@@ -583,10 +587,11 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s,
 
 }  // namespace ay
 
-extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const float* scale0, const float* shift0, int leaky0,
-                                    const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
-                                    int batch, int h, int w, ay_stream_t stream) {
-    using namespace ay;
+namespace ay {
+template <typename DT>
+static int stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const float* scale0, const float* shift0, int leaky0,
+                             const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
+                             int batch, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(x_nchw && stem_w_bf16 && scale0 && shift0 && w1_packed && scale1 && shift1 && out_blocked, "ay_stem_s2_fused_fwd: null");
     AY_CHECK_ARG(batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "ay_stem_s2_fused_fwd: even image sizes only");
     StemFusedArgs s;
@@ -632,9 +637,9 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     const int cu_slots = conv_num_cus() / 8;
     dim3 grid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots)));
     if (v2)
-        hipLaunchKernelGGL(stem_s2_fused_v2_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
+        hipLaunchKernelGGL(stem_s2_fused_v2_kernel<DT>, grid, dim3(1024), 0, S(stream), s, (int)n_items);
     else
-        hipLaunchKernelGGL(stem_s2_fused_kernel, grid, dim3(1024), 0, S(stream), s, (int)n_items);
+        hipLaunchKernelGGL(stem_s2_fused_kernel<DT>, grid, dim3(1024), 0, S(stream), s, (int)n_items);
     AY_CHECK_LAUNCH("stem_s2_fused_kernel");
 #ifdef AY_PHASE_CLOCK
     if (getenv("AY_DBG") && (atoi(getenv("AY_DBG")) & 8)) {
@@ -651,4 +656,16 @@ extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16
     }
 #endif
     return AY_OK;
+}
+}  // namespace ay
+
+extern "C" int ay_stem_s2_fused_fwd(const float* x_nchw, const void* stem_w_bf16, const float* scale0, const float* shift0, int leaky0,
+                                    const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
+                                    int batch, int h, int w, ay_stream_t stream) {
+    return ay::stem_s2_fused_fwd<ay::Bf16>(x_nchw, stem_w_bf16, scale0, shift0, leaky0, w1_packed, scale1, shift1, leaky1, out_blocked, batch, h, w, stream);
+}
+extern "C" int ay_stem_s2_fused_fwd_f16(const float* x_nchw, const void* stem_w_f16, const float* scale0, const float* shift0, int leaky0,
+                                        const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
+                                        int batch, int h, int w, ay_stream_t stream) {
+    return ay::stem_s2_fused_fwd<ay::F16>(x_nchw, stem_w_f16, scale0, shift0, leaky0, w1_packed, scale1, shift1, leaky1, out_blocked, batch, h, w, stream);
 }

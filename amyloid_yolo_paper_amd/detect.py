@@ -18,11 +18,23 @@ from .utils import load_classes, non_max_suppression, rescale_boxes
 
 def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_path="weights/yolov3.weights",
            class_path=None, conf_thres=0.8, nms_thres=0.4, batch_size=1, n_cpu=0, img_size=416, precision="bf16",
-           rescale=True, verbose=True, device_ingest=True, merge_boxes=False):
-    """``device_ingest``: upload the decoded uint8 tiles and do /255 + pad-to-square + nearest resize on the GPU
+           rescale=True, verbose=True, device_ingest=True, merge_boxes=False, write_CAA_detections_to_pickle=False,
+           filter_CAA_detections_by_model=False):
+    """``precision``: "bf16" | "fp16" (the two 16-bit MFMA storage types) | "fp32" (reference-precision parity path).
+    ``device_ingest``: upload the decoded uint8 tiles and do /255 + pad-to-square + nearest resize on the GPU
     (``ay_ingest_tiles_u8``, bit-identical to the host transforms); batches of mixed image sizes are ingested one size at a time.
     ``merge_boxes``: the reference's ``--merge_boxes True`` (``detect.py:131-133``): union-merge overlapping same-class boxes
-    after the rescale (``postprocess.merge_detections``)."""
+    after the rescale (``postprocess.merge_detections``).
+    ``write_CAA_detections_to_pickle`` / ``filter_CAA_detections_by_model`` (reference ``detect.py:43-44,134-141``) belong to the
+    paper's second-stage CAA classifier (``core.filterDetectionsByCAAModel`` / ``writeCAADetectionsToPickle``: cv2, skimage and
+    a Git-LFS model pickle): accepted so that existing command lines parse, refused with a clear error when switched on."""
+    for flag, on in (("write_CAA_detections_to_pickle", write_CAA_detections_to_pickle),
+                     ("filter_CAA_detections_by_model", filter_CAA_detections_by_model)):
+        if on:
+            raise NotImplementedError(
+                f"--{flag} True: the second-stage CAA model of the reference (core.py:425-480; needs cv2, skimage and the Git-LFS "
+                "pickle CAA_consensus_of_2_model) is outside this library's scope (SURVEY.md section 2); run detect() without it "
+                "and post-process the returned detections with the reference's core.py")
     model = Darknet(model_def, img_size=img_size, precision=precision).to("cuda")
     if weights_path.endswith(".weights"):
         model.load_darknet_weights(weights_path)
@@ -79,12 +91,16 @@ def main(argv=None):
     ap.add_argument("--n_cpu", type=int, default=0)
     ap.add_argument("--img_size", type=int, default=416)
     ap.add_argument("--checkpoint_model", type=str)
-    ap.add_argument("--precision", type=str, default="bf16")
+    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--merge_boxes", type=str, default="False", help="merge overlapping boxes of the same class (reference detect.py:42)")
+    ap.add_argument("--write_CAA_detections_to_pickle", type=str, default="False", help="reference detect.py:43 -- out of scope: errors when True")
+    ap.add_argument("--filter_CAA_detections_by_model", type=str, default="False", help="reference detect.py:44 -- out of scope: errors when True")
     opt = ap.parse_args(argv)
     paths, results, classes = detect(opt.image_folder, opt.model_def, opt.weights_path, opt.class_path, opt.conf_thres,
                                      opt.nms_thres, opt.batch_size, opt.n_cpu, opt.img_size, opt.precision,
-                                     merge_boxes=opt.merge_boxes == "True")
+                                     merge_boxes=opt.merge_boxes == "True",
+                                     write_CAA_detections_to_pickle=opt.write_CAA_detections_to_pickle == "True",
+                                     filter_CAA_detections_by_model=opt.filter_CAA_detections_by_model == "True")
     for path, det in zip(paths, results):
         print(f"Image: '{path}'")
         if det is None:

@@ -7,6 +7,8 @@ forward itself is a planned sequence of calls into ``libamyloid_yolo_hip.so``:
 
 * ``precision="bf16"`` (default): fp32 stem -> blocked-bf16 MFMA convolutions with fused
   BN-affine/LeakyReLU/shortcut epilogues, route+upsample gather, fp32 linear heads, fused decode.
+* ``precision="fp16"``: the same plan and kernels on IEEE half storage (``v_mfma_*_f16``; inference only -- BASELINE.json
+  configs[4]'s "fp16 MFMA path"): identical bytes and MFMA rate, an 8x smaller rounding step per stored activation.
 * ``precision="fp32"``: every block through the fp32 nchw kernel (reference layout, reference
   precision) -- the mode the 1e-4 parity tests run.
 
@@ -122,7 +124,7 @@ class Darknet(nn.Module):
         self.img_size = img_size
         self.seen = 0
         self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
-        assert precision in ("bf16", "fp32")
+        assert precision in ("bf16", "fp16", "fp32")
         self.precision = precision
         # residual blocks run through the fused kernel: C=64 (measured 1.74 ms vs 2.37 for the two launches at B=64, 512^2);
         # the C=128 kernel exists (ay_resblock_supported) but measures 1.15 vs 1.04 ms, so it is not used by default
@@ -292,24 +294,40 @@ class Darknet(nn.Module):
                 bias = conv.bias.detach().to(device=device, dtype=torch.float32).contiguous()
                 check(L.ay_fold_bn(None, None, None, None, ptr(bias), C.c_float(0.0), ptr(scale), ptr(shift), cout, cpad, st),
                       "ay_fold_bn")
-            entry = dict(scale=scale, shift=shift, cpad=cpad, w=w, stem=first and self.precision == "bf16")
-            if entry["stem"]:  # [32][32] bf16 A-operand image of the stem filters for the fused stem kernel (k 27..31 = 0)
+            entry = dict(scale=scale, shift=shift, cpad=cpad, w=w, stem=first and self._mfma)
+            if entry["stem"]:  # [32][32] 16-bit A-operand image of the stem filters for the fused stem kernel (k 27..31 = 0)
                 w0 = torch.zeros(32, 32, device=device, dtype=torch.float32)
                 w0[:, :27] = w.reshape(32, 27)
-                entry["w0_bf16"] = w0.to(torch.bfloat16).contiguous()
-            if self.precision == "bf16" and not entry["stem"]:
+                entry["w0_bf16"] = w0.to(self._act_dtype).contiguous()
+            if self._mfma and not entry["stem"]:
                 assert e["cin"] % 16 == 0, f"layer {i}: cin {e['cin']} is not a multiple of 16"
                 # blocked bf16 values are sized and strided in 16-channel planes of ceil16(channels); the kernels write
                 # cout_pad = ceil32(cout) channels: a BN layer with filters % 32 == 16 would write one plane per image too many
                 assert not e["bn"] or cout % 32 == 0, f"layer {i}: the bf16 path needs a multiple of 32 filters in conv+BN layers (got {cout}); use precision='fp32'"
                 nbytes = L.ay_packed_weight_bytes(cpad, e["cin"], e["k"])
                 packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
-                check(L.ay_pack_conv_weights_bf16(ptr(w), ptr(packed), cout, cpad, e["cin"], e["k"], st), "ay_pack_conv_weights_bf16")
+                check(self._fn("ay_pack_conv_weights")(ptr(w), ptr(packed), cout, cpad, e["cin"], e["k"], st), "ay_pack_conv_weights")
                 entry["packed"] = packed
             prep["layers"][i] = entry
         torch.cuda.current_stream().synchronize()  # temporaries (g,b_,mu,var,bias) die here
         self._prep = prep
         return prep
+
+    # ------------------------------------------------------------------ storage type of the MFMA path
+    @property
+    def _mfma(self):
+        return self.precision in ("bf16", "fp16")
+
+    @property
+    def _act_dtype(self):
+        return torch.float16 if self.precision == "fp16" else torch.bfloat16
+
+    def _fn(self, stem):
+        """entry point ``stem``_bf16 | ``stem``_f16 of the library for this model's 16-bit storage type"""
+        L = _lib.lib()
+        if stem in ("ay_stem_s2_fused_fwd", "ay_stem_conv_fwd"):  # the bfloat16 forms carry no suffix
+            return getattr(L, stem + ("_f16" if self.precision == "fp16" else ""))
+        return getattr(L, stem + ("_f16" if self.precision == "fp16" else "_bf16"))
 
     def _unit(self, n, dev):
         """cached (ones[n], zeros[n]) device vectors: identity scale/shift for raw convolutions"""
@@ -331,6 +349,7 @@ class Darknet(nn.Module):
             # training step: loss carries the autograd node whose backward runs the HIP dgrad / wgrad / BN / loss kernels
             # and fills every parameter's .grad.  precision="bf16": matrix-core path (train_engine_bf16.py);
             # precision="fp32": reference-precision path pinned by the golden training fixtures (train_engine.py).
+            self._no_fp16_training()
             if self.precision == "bf16" and self.training:
                 from .train_engine_bf16 import TrainStepBf16 as Step
             else:
@@ -338,6 +357,7 @@ class Darknet(nn.Module):
             loss, dev_out = Step.apply(self, x, targets, *self.parameters())
             return loss, dev_out.detach().cpu()
         if self.training:
+            self._no_fp16_training()
             if self.precision == "bf16":
                 from .train_engine_bf16 import train_forward_bf16 as fwd
             else:
@@ -352,8 +372,14 @@ class Darknet(nn.Module):
         out._ay_device = dev_out
         return out
 
+    def _no_fp16_training(self):
+        if self.precision == "fp16":
+            raise _lib.AyError("precision='fp16' is an inference storage type (no loss scaling, 5-bit exponent): train with "
+                               "precision='bf16' (or 'fp32') and switch to fp16 for detection -- the weights are fp32 either way")
+
     def train_step_device(self, x, targets):
         """training forward with the autograd node attached, outputs left on the device: (loss, out [B,N,5+C] cuda)"""
+        self._no_fp16_training()
         if self.precision == "bf16" and self.training:
             from .train_engine_bf16 import TrainStepBf16 as Step
         else:
@@ -374,7 +400,7 @@ class Darknet(nn.Module):
         assert Cin == int(self.hyperparams["channels"])
         prep = self._prepare(dev)
         st = _lib.stream_ptr()
-        bf16 = self.precision == "bf16"
+        bf16 = self._mfma   # the 16-bit MFMA path, bfloat16 or half storage
         key = (self.precision, B, S)
         bufs = self._act_bufs.setdefault(key, {})
         C_ = self.yolo_layers[0].num_classes
@@ -398,7 +424,7 @@ class Darknet(nn.Module):
                 elif f32:
                     bufs[i] = torch.empty(B, _pad_to(c, 32) // 16, h, h, 16, device=dev, dtype=torch.float32)
                 else:
-                    bufs[i] = torch.empty(B, _pad_to(c, 16) // 16, h, h, 16, device=dev, dtype=torch.bfloat16)
+                    bufs[i] = torch.empty(B, _pad_to(c, 16) // 16, h, h, 16, device=dev, dtype=self._act_dtype)
             return bufs[i]
 
         prof = getattr(self, "profile_layers", None)  # bench.py: bracket these conv launches with HIP events
@@ -447,7 +473,7 @@ class Darknet(nn.Module):
                     assert L.ay_resblock_supported(e["cin"])
                     xin = resolve(e["src"])
                     o = buf(i + 2)
-                    check(L.ay_resblock_fwd_bf16(ptr(xin), ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]), int(e["leaky"]),
+                    check(self._fn("ay_resblock_fwd")(ptr(xin), ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]), int(e["leaky"]),
                                                  ptr(p2["packed"]), ptr(p2["scale"]), ptr(p2["shift"]), int(e2["leaky"]), ptr(o), B,
                                                  e["cin"], hout, hout, st), "ay_resblock_fwd_bf16")
                     val[i] = ("fused", None)
@@ -460,7 +486,7 @@ class Darknet(nn.Module):
                 if bf16 and i == 1 and val.get(0, (None,))[0] == "fused":
                     p0 = prep["layers"][0]
                     o = buf(tgt)
-                    check(L.ay_stem_s2_fused_fwd(ptr(x), ptr(p0["w0_bf16"]), ptr(p0["scale"]), ptr(p0["shift"]), int(self._graph[0]["leaky"]),
+                    check(self._fn("ay_stem_s2_fused_fwd")(ptr(x), ptr(p0["w0_bf16"]), ptr(p0["scale"]), ptr(p0["shift"]), int(self._graph[0]["leaky"]),
                                                  ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]), int(e["leaky"]), ptr(o), B, S, S, st),
                           "ay_stem_s2_fused_fwd")
                     val[i] = ("t", o)
@@ -468,14 +494,14 @@ class Darknet(nn.Module):
                 if bf16:
                     if p["stem"]:
                         o = buf(tgt)
-                        check(L.ay_stem_conv_fwd(ptr(x), ptr(p["w"]), ptr(p["scale"]), ptr(p["shift"]), ptr(o), B, S, S,
+                        check(self._fn("ay_stem_conv_fwd")(ptr(x), ptr(p["w"]), ptr(p["scale"]), ptr(p["shift"]), ptr(o), B, S, S,
                                                  int(e["leaky"]), st), "ay_stem_conv_fwd")
                     elif e["src"] >= 0 and val[e["src"]][0] == "catup":
                         ra, rb = val[e["src"]][1]
                         s1 = resolve(val[ra][1])      # half-resolution source of the lazy upsample
                         s2 = resolve(rb)
                         o = buf(tgt)
-                        check(L.ay_conv1x1_cat_fwd_bf16(C.byref(d), ptr(s1), self._graph[ra]["channels"], ptr(s2), ptr(p["packed"]),
+                        check(self._fn("ay_conv1x1_cat_fwd")(C.byref(d), ptr(s1), self._graph[ra]["channels"], ptr(s2), ptr(p["packed"]),
                                                         ptr(p["scale"]), ptr(p["shift"]), ptr(o), st), "ay_conv1x1_cat_fwd_bf16")
                     else:
                         src = x if e["src"] < 0 else resolve(e["src"])
@@ -486,7 +512,7 @@ class Darknet(nn.Module):
                         if timed:
                             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             ev0.record()
-                        check(L.ay_conv_fwd_bf16(C.byref(d), ptr(src), ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]),
+                        check(self._fn("ay_conv_fwd")(C.byref(d), ptr(src), ptr(p["packed"]), ptr(p["scale"]), ptr(p["shift"]),
                                                  ptr(res), ptr(o), st), "ay_conv_fwd_bf16")
                         if timed:
                             ev1.record()
@@ -547,7 +573,7 @@ class Darknet(nn.Module):
         """The bf16 walk of ``forward_device`` with symbolic values: the op list (``_lib.PlanOp``) and the byte size of every
         value, for ``ay_plan_create``.  Same decisions as the per-layer walk (fused stem, fused block, route folded into the 1x1
         loader, lazy upsample), so both issue the same kernels with the same arguments."""
-        assert self.precision == "bf16"
+        assert self._mfma
         ops, vbytes, val = [], [], {}
         N = self.num_boxes(S)
 
@@ -691,7 +717,8 @@ class Darknet(nn.Module):
             arr = (_lib.PlanOp * len(ops))(*ops)
             vb = (C.c_size_t * len(vbytes))(*vbytes)
             handle = C.c_void_p()
-            check(L.ay_plan_create(arr, len(ops), vb, len(vbytes), S, self.num_boxes(S), C.byref(handle)), "ay_plan_create")
+            check(L.ay_plan_create(arr, len(ops), vb, len(vbytes), S, self.num_boxes(S), int(self.precision == "fp16"), C.byref(handle)),
+                  "ay_plan_create")
             ws = torch.empty(L.ay_plan_workspace_bytes(handle), device=dev, dtype=torch.uint8)
             plans[key] = _Plan(handle, ws, ops, sum(vbytes))
         return plans[key]
@@ -753,6 +780,6 @@ class Darknet(nn.Module):
         B, P, H, W, _ = t.shape
         c = self._graph[i]["channels"]
         o = torch.empty(B, c, H, W, device=t.device, dtype=torch.float32)
-        fn = L.ay_blocked_bf16_to_nchw_f32 if t.dtype == torch.bfloat16 else L.ay_blocked_f32_to_nchw_f32
+        fn = {torch.bfloat16: L.ay_blocked_bf16_to_nchw_f32, torch.float16: L.ay_blocked_f16_to_nchw_f32}.get(t.dtype, L.ay_blocked_f32_to_nchw_f32)
         check(fn(ptr(t), ptr(o), B, c, H, W, _lib.stream_ptr()), "blocked_to_nchw")
         return o

@@ -180,5 +180,4 @@ class FlatAdam:
         _lib.check(_lib.lib().ay_adam_flat(_lib.ptr(self.flat), _lib.ptr(self.red.flat), _lib.ptr(self.m), _lib.ptr(self.v), self.flat.numel(),
                                             C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                             self.step_count, C.c_float(grad_scale), _lib.stream_ptr()), "ay_adam_flat")
-        for p in self.red.params:   # the packed/derived copies of the weights are stale now
-            p._version  # (touching nothing: models.Darknet keys its caches on data_ptr/_version; training re-packs per step)
+        # (the packed / derived copies of the weights are stale now: the training engine re-packs when WEIGHT_EPOCH moves)

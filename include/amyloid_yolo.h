@@ -34,6 +34,13 @@ extern "C" {
 
 typedef void* ay_stream_t; /* hipStream_t */
 
+/* 16-bit storage type of the MFMA path's activations and packed filters.  Same layouts, bytes and MFMA rate; bfloat16 keeps
+ * fp32's exponent range (training, default), IEEE half (inference only: the *_f16 entry points below) has an 11-bit
+ * significand -- an 8x smaller rounding step per stored activation (BASELINE.json configs[4] "fp16 MFMA path") -- and is
+ * finite up to 65504: stored activations are post-BatchNorm, heads leave the path as fp32. */
+#define AY_DT_BF16 0
+#define AY_DT_F16 1
+
 int ay_version(void);
 const char* ay_last_error(void);
 
@@ -114,6 +121,30 @@ int ay_concat_upsample_bf16(const void* src1, int c1, int up1, const void* src2,
 int ay_blocked_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream);
 int ay_blocked_f32_to_nchw_f32(const float* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream);
 int ay_nchw_f32_to_blocked_bf16(const float* src, void* dst, int batch, int c, int h, int w, ay_stream_t stream);
+
+/* ---- the same inference entry points on IEEE half ("blocked f16": [B][C/16][H][W][16] half; packed filters half) ----------
+ * Identical arguments, layouts, fusion and rounding points (operands 16-bit, fp32 accumulate, fp32 epilogue, ONE rounding per
+ * stored activation -- to half instead of bfloat16); v_mfma_f32_{32x32x16,16x16x32}_f16 in place of the _bf16 forms.
+ * ay_concat_upsample_bf16 moves 16-bit elements untouched and serves both types.  Replaces the same reference lines as the
+ * _bf16 entry point of the same name (models.py:26-45, 86-96, 244-248). */
+int ay_pack_conv_weights_f16(const float* w_oihw, void* packed, int cout, int cout_pad, int cin, int ksize, ay_stream_t stream);
+int ay_stem_conv_fwd_f16(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                         void* out_blocked, int batch, int h, int w, int leaky, ay_stream_t stream);
+/* stem_w_f16: [32][32] half, k = ci*9+kh*3+kw (27..31 zero) */
+int ay_stem_s2_fused_fwd_f16(const float* x_nchw, const void* stem_w_f16, const float* scale0, const float* shift0, int leaky0,
+                             const void* w1_packed, const float* scale1, const float* shift1, int leaky1, void* out_blocked,
+                             int batch, int h, int w, ay_stream_t stream);
+int ay_conv_fwd_f16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
+                    const float* shift, const void* residual, void* out, ay_stream_t stream);
+int ay_conv3x3_m16_fwd_f16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                           const void* residual, void* out, ay_stream_t stream);
+int ay_conv1x1_cat_fwd_f16(const ay_conv_desc* d, const void* src1_halfres, int c1, const void* src2, const void* w_packed,
+                           const float* scale, const float* shift, void* out, ay_stream_t stream);
+int ay_resblock_fwd_f16(const void* x, const void* w1_packed, const float* scale1, const float* shift1, int leaky1,
+                        const void* w2_packed, const float* scale2, const float* shift2, int leaky2, void* out, int batch,
+                        int channels, int h, int w, ay_stream_t stream);
+int ay_blocked_f16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h, int w, ay_stream_t stream);
+int ay_nchw_f32_to_blocked_f16(const float* src, void* dst, int batch, int c, int h, int w, ay_stream_t stream);
 
 /* ---- fp32 parity path (reference layout) ------------------------------------------------------ */
 
@@ -359,9 +390,11 @@ typedef struct ay_plan_op {
     const float* shift2;
 } ay_plan_op;
 typedef struct ay_plan ay_plan;
-/* value_bytes[i] = size of value i.  Fails (AY_ERR_ARG) on a value read before it is written or never written. */
+/* value_bytes[i] = size of value i.  Fails (AY_ERR_ARG) on a value read before it is written or never written.
+ * act_dtype: AY_DT_BF16 | AY_DT_F16 -- the storage type of the blocked activations and of every packed filter image in `ops`
+ * (the plan then issues the _bf16 or the _f16 entry points). */
 int ay_plan_create(const ay_plan_op* ops, int n_ops, const size_t* value_bytes, int n_values, int img_dim, int n_total_rows,
-                   ay_plan** out_plan);
+                   int act_dtype, ay_plan** out_plan);
 void ay_plan_destroy(ay_plan* plan);
 size_t ay_plan_workspace_bytes(const ay_plan* plan);       /* 256-byte aligned arena the caller allocates */
 size_t ay_plan_value_offset(const ay_plan* plan, int value); /* where a value lives in the arena (tests) */

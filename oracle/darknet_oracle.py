@@ -13,6 +13,9 @@ bfloat16 per stored activation; the three linear heads (fp32 out) are not rounde
 The stem takes the fp32 image: with ``stem_bf16=True`` (the fused stem kernel, default) image and stem filters are
 rounded to bfloat16 like every other operand, with ``stem_bf16=False`` (the separate fp32 stem kernel) they are not.
 
+``mode="fp16"`` is the same contract with IEEE half in the place of bfloat16 (``precision="fp16"`` of the HIP path: the
+same rounding points -- operands, one rounding per stored activation -- with an 11-bit significand instead of 8).
+
 ``mode="bf16_train"`` is the numeric contract of the HIP bf16 TRAINING step (``train_engine_bf16.py``): as ``bf16``, and
 in addition the raw convolution output z of a BN layer is rounded to bfloat16 before the batch statistics are taken (the
 training path stores z and normalises in a second pass).  Every rounding is a straight-through estimator
@@ -63,6 +66,15 @@ def giou_cxcywh(b1, b2):
 
 def _bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _fp16(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def _ulp(mode):
+    """relative size of one rounding step of the storage type of `mode`"""
+    return 2.0 ** -10 if mode == "fp16" else 2.0 ** -7
 
 
 def _ulp_report(own, forced, f32=False):
@@ -143,10 +155,11 @@ class OracleDarknet:
         k, s = int(d["size"]), int(d["stride"])
         w = p["weight"]
         first = x.shape[1] == int(self.hyper["channels"]) and i == 0
-        if mode == "bf16" and (not first or stem_bf16):
-            w = _bf16(w)
+        if mode in ("bf16", "fp16") and (not first or stem_bf16):
+            r16 = _bf16 if mode == "bf16" else _fp16
+            w = r16(w)
             if first:
-                x = _bf16(x)
+                x = r16(x)
         if mode == "bf16_train":
             w = _ste(w)
             if first:
@@ -203,7 +216,7 @@ class OracleDarknet:
         outs_r, outs_f = [], []  # stored (rounded) and unrounded fp32 value of every layer output
         yolo_out, loss = [], 0
         self.metrics = []
-        rnd = _bf16 if mode == "bf16" else _ste if mode == "bf16_train" else (lambda t: t)
+        rnd = _bf16 if mode == "bf16" else _fp16 if mode == "fp16" else _ste if mode == "bf16_train" else (lambda t: t)
         for i, d in enumerate(self.defs):
             t = d["type"]
             if t == "convolutional":

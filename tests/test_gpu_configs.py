@@ -25,17 +25,23 @@ pytestmark = pytest.mark.gpu
 # float64 convolution sums): 0.817 / 0.835 of the reference's 230 kept indices, 0.126 / 0.090 extra heads, confidences of
 # matched heads within 0.023, boxes of matched heads within 0.33 of the box size (a head whose cluster gained or lost a
 # member moves with the conf-weighted merge, utils/utils.py:259-269).  The HIP path is held to the contract's own level:
-KEEP_MATCH_MIN = 0.78      # fraction of the reference's kept box indices (cluster heads) that the bf16 path keeps too
-EXTRA_HEADS_MAX = 0.16     # fraction of the bf16 path's heads that the reference does not have
-BOX_REL_MAX = 0.40         # matched heads: max corner difference relative to the box size (merge membership may differ)
-DCONF_MAX = 0.03           # matched heads: max |confidence difference|
+# Round 3: the same contract on IEEE-half storage (precision="fp16", an 11-bit significand against bf16's 8: every rounding step 8x
+# smaller, same bytes, same MFMA rate) attains, by the CPU oracle in mode="fp16" on this tile (fp32 / float64 sums): 0.9957 / 1.0 of
+# the 230 kept indices, 0.017 / 0.021 extra heads, matched confidences within 0.0027, matched boxes within 0.168 of the box size
+# (one cluster gains a member).  The half path is the bench default and is held to that level.
+BARS = {   # keep_match >=, extra_heads <=, max_box_rel <=, max_dconf <=, decoded-sample dconf q99 <=, box rel q99.9 <=
+    "bf16": (0.78, 0.16, 0.40, 0.03, 2e-2, 5e-2),
+    "fp16": (0.98, 0.035, 0.20, 0.004, 2.5e-3, 6.25e-3),
+}
 
 
-def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir, precision):
+    KEEP_MATCH_MIN, EXTRA_HEADS_MAX, BOX_REL_MAX, DCONF_MAX, DCONF_Q99, REL_Q999 = BARS[precision]
     dev = torch.device("cuda", 0)
     name, C_, S, B1, start = [c for c in gc.MODEL_CASES if c[0] == "c3_s1024_b1"][0]
     z = load(golden_dir, "model_" + name)
-    m, _ = build_models(C_, tmp_cfg_dir, dev, "bf16")
+    m, _ = build_models(C_, tmp_cfg_dir, dev, precision)
     assert m.use_plan and not m.keep_layer_outputs
     x1 = torch.from_numpy(gc.model_inputs(S, B1, start))            # the fixture's tile
     out1 = m.forward_device(x1).clone()
@@ -55,7 +61,7 @@ def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir):
         assert np.array_equal(res.keep_idx[b], res.keep_idx[0]) and torch.equal(res[b], res[0])
     agree = parity.detection_agreement(z["nms_keep0"], z["nms_rows0"], res.keep_idx[0], res[0].cpu().numpy())
     s = parity.summarize([agree])
-    print("configs[1] bf16 vs reference fixture:", s)
+    print(f"configs[1] {precision} vs reference fixture:", s)
     assert s["keep_match"] >= KEEP_MATCH_MIN and s["extra_heads"] <= EXTRA_HEADS_MAX, s
     assert s["max_box_rel"] <= BOX_REL_MAX and s["max_dconf"] <= DCONF_MAX and agree["cls_equal"], s
     # decoded rows of the fixture's sample: confidences / classes within bf16 noise, boxes relative to their size
@@ -64,7 +70,7 @@ def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir):
     dconf = np.abs(got[:, 4:] - ref[:, 4:])
     rel = np.abs(got[:, :4] - ref[:, :4]) / np.maximum(1.0, ref[:, 2:4].max(-1, keepdims=True))
     print("decoded sample: dconf q99 %.4f max %.4f, box rel q99.9 %.4f" % (np.quantile(dconf, 0.99), dconf.max(), np.quantile(rel, 0.999)))
-    assert np.quantile(dconf, 0.99) <= 2e-2 and np.quantile(rel, 0.999) <= 5e-2
+    assert np.quantile(dconf, 0.99) <= DCONF_Q99 and np.quantile(rel, 0.999) <= REL_Q999
 
 
 def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):

@@ -39,16 +39,16 @@ def reads_of(o):
     return r
 
 
-def create(ops, vbytes, S, N):
+def create(ops, vbytes, S, N, dtype=0):
     L = _lib.lib()
     arr = (PlanOp * len(ops))(*ops)
     vb = (C.c_size_t * len(vbytes))(*vbytes)
     h = C.c_void_p()
-    rc = L.ay_plan_create(arr, len(ops), vb, len(vbytes), S, N, C.byref(h))
+    rc = L.ay_plan_create(arr, len(ops), vb, len(vbytes), S, N, dtype, C.byref(h))
     return rc, h
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(fuse_blocks=False, fold_routes=False), dict(stem_mode="fp32")], ids=str)
+@pytest.mark.parametrize("opts", [dict(), dict(fuse_blocks=False, fold_routes=False), dict(stem_mode="fp32"), dict(precision="fp16")], ids=str)
 def test_lowering_and_arena(tmp_cfg_dir, opts):
     L = _lib.lib()
     m = Darknet(cfg_gen.write_cfg(3, tmp_cfg_dir))
@@ -59,7 +59,7 @@ def test_lowering_and_arena(tmp_cfg_dir, opts):
     ops, vbytes = m._lower(B, S, fake_prep(m))
     kinds = [o.kind for o in ops]
     assert kinds.count(_lib.OP_DECODE) == 3
-    if not opts:
+    if not opts or "precision" in opts:   # the half-precision plan is the same op list on the other storage type
         assert kinds[0] == _lib.OP_STEM_S2_FUSED and kinds.count(_lib.OP_RESBLOCK) == 1 and kinds.count(_lib.OP_CONV1X1_CAT) == 2
         assert kinds.count(_lib.OP_CONCAT_UPSAMPLE) == 0          # both routes ride the 1x1 loader
         assert len(ops) == 75 - 1 - 1 + 3                         # 75 convs; the stem pair and one block are one op each; 3 decodes
@@ -67,7 +67,7 @@ def test_lowering_and_arena(tmp_cfg_dir, opts):
         assert kinds.count(_lib.OP_CONCAT_UPSAMPLE) == 2 and kinds.count(_lib.OP_RESBLOCK) == 0
     if opts.get("stem_mode") == "fp32":
         assert kinds[0] == _lib.OP_STEM
-    rc, h = create(ops, vbytes, S, m.num_boxes(S))
+    rc, h = create(ops, vbytes, S, m.num_boxes(S), int(m.precision == "fp16"))
     assert rc == 0, L.ay_last_error()
     try:
         arena = L.ay_plan_workspace_bytes(h)
@@ -108,6 +108,8 @@ def test_plan_rejects_broken_dataflow():
                       ([stem, conv(0, 1, res=2)], b"before it is written")):
         rc, h = create(ops, [64, 64, 64], 32, 3)
         assert rc == -1 and what in L.ay_last_error(), (what, L.ay_last_error())
+    rc, h = create([stem, conv(0, 1)], [64, 64], 32, 3, dtype=5)
+    assert rc == -1 and b"dtype" in L.ay_last_error()
     rc, h = create([stem, conv(0, 1), conv(1, 2, res=0)], [1000, 300, 300], 32, 3)
     assert rc == 0
     assert L.ay_plan_workspace_bytes(h) == 1024 + 512 + 512          # all three alive at the last op
