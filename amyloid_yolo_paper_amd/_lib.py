@@ -48,6 +48,7 @@ _SIGS = {
     "ay_blocked_f32_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_nchw_f32_to_blocked_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_conv_fwd_f32": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ay_conv_fwd_f32_valu": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ay_yolo_decode": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _P]),
     "ay_xywh2xyxy": (_I, [_P, _I64, _I, _P]),
     "ay_box_iou": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
@@ -88,6 +89,8 @@ _SIGS = {
     "ay_bn_train_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_bn_train_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ay_bn_train_bwd_bf16_acc": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ay_bn_train_fwd_bf16_zeroed_ws": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ay_bn_train_bwd_bf16_acc_zeroed_ws": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ay_accumulate_bf16": (_I, [_P, _P, _SZ, _P]),
     "ay_slice_accumulate_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ay_zero_insert_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -117,6 +120,7 @@ _SIGS = {
     "ay_resblock_fwd_f16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ay_blocked_f16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_nchw_f32_to_blocked_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ay_stream_fence": (_I, [_P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

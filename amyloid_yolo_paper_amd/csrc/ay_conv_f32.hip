@@ -72,9 +72,9 @@ int conv_fwd_f32_mfma(const ay_conv_desc* d, const float* src1, int cin1, int up
 
 }  // namespace ay
 
-extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
-                               const float* w_oihw, const float* scale, const float* shift, const float* residual, float* out,
-                               ay_stream_t stream) {
+static int conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
+                        const float* w_oihw, const float* scale, const float* shift, const float* residual, float* out,
+                        ay_stream_t stream, bool allow_mfma) {
     using namespace ay;
     AY_CHECK_ARG(d && src1 && w_oihw && scale && shift && out, "ay_conv_fwd_f32: null argument");
     AY_CHECK_ARG(cin1 > 0 && cin1 <= d->cin && (cin1 == d->cin || src2), "ay_conv_fwd_f32: channel split %d/%d", cin1, d->cin);
@@ -82,9 +82,11 @@ extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin
     const int pad = (d->ksize - 1) / 2;
     AY_CHECK_ARG(d->hout == (d->hin + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (d->win + 2 * pad - d->ksize) / d->stride + 1,
                  "ay_conv_fwd_f32: output size mismatch");
-    bool taken = false;
-    const int rc = conv_fwd_f32_mfma(d, src1, cin1, up1, src2, w_oihw, scale, shift, residual, out, S(stream), &taken);
-    if (taken) return rc;
+    if (allow_mfma) {
+        bool taken = false;
+        const int rc = conv_fwd_f32_mfma(d, src1, cin1, up1, src2, w_oihw, scale, shift, residual, out, S(stream), &taken);
+        if (taken) return rc;
+    }
     const int cgroups = (d->cout + CO_T - 1) / CO_T;
     const long long gz = (long long)d->batch * cgroups;
     AY_CHECK_ARG(gz <= 65535, "ay_conv_fwd_f32: batch*cout/4 = %lld exceeds grid.z", gz);
@@ -93,4 +95,20 @@ extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin
                        d->cin, d->cout, d->hin, d->win, d->hout, d->wout, d->ksize, d->stride, d->leaky);
     AY_CHECK_LAUNCH("conv_f32_kernel");
     return AY_OK;
+}
+
+extern "C" int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
+                               const float* w_oihw, const float* scale, const float* shift, const float* residual, float* out,
+                               ay_stream_t stream) {
+    return conv_fwd_f32(d, src1, cin1, up1, src2, w_oihw, scale, shift, residual, out, stream, true);
+}
+
+// The same block on the VALU kernel only: one fmaf chain per output in (ci, kh, kw) order.  The fp32 TRAINING engine
+// (train_engine.py) keeps this form: its step is pinned element-wise against the reference's own training fixtures
+// (tests/golden/train_*.npz), and below a LeakyReLU a gradient comparison is sensitive to the summation order of the forward
+// (a pre-activation within 1e-5 of zero takes the other slope; tests/test_gpu_train.py) -- the bars there were set on this order.
+extern "C" int ay_conv_fwd_f32_valu(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
+                                    const float* w_oihw, const float* scale, const float* shift, const float* residual, float* out,
+                                    ay_stream_t stream) {
+    return conv_fwd_f32(d, src1, cin1, up1, src2, w_oihw, scale, shift, residual, out, stream, false);
 }

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ay_common.h"  // pulls in include/amyloid_yolo.h
@@ -242,4 +243,37 @@ extern "C" int ay_plan_forward_timed(const ay_plan* plan, const float* x_nchw, v
         if (e) (void)hipEventDestroy(e);
     if (rc == AY_ERR_LAUNCH) ay::set_error("ay_plan_forward_timed: HIP event / stream error");
     return rc;
+}
+
+// A stream-ordered fence owned by the library: an event recorded on `stream` and waited for by the same stream (no host wait).
+// The events live in a small per-process table keyed by stream and are re-recorded on every call.
+extern "C" int ay_stream_fence(ay_stream_t stream) {
+    struct Slot {
+        hipStream_t st;
+        int dev;
+        hipEvent_t ev;
+    };
+    static std::mutex mu;
+    static std::vector<Slot> slots;
+    hipStream_t st = ay::S(stream);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Slot& s : slots)
+            if (s.st == st && s.dev == dev) ev = s.ev;
+        if (!ev) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                ay::set_error("ay_stream_fence: hipEventCreate failed");
+                return AY_ERR_LAUNCH;
+            }
+            slots.push_back({st, dev, ev});
+        }
+    }
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(st, ev, 0) != hipSuccess) {
+        ay::set_error("ay_stream_fence: event record / stream wait failed");
+        return AY_ERR_LAUNCH;
+    }
+    return AY_OK;
 }

@@ -456,13 +456,13 @@ static inline unsigned gridu(size_t units) {
 
 using namespace ay;
 
-extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                    float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
-                                    double* sums_ws /* 2*C doubles */, int batch, int channels, int h, int w, ay_stream_t stream) {
+static int bn_train_fwd(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                        double* sums_ws /* 2*C doubles */, bool ws_is_zero, int batch, int channels, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(z && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && sums_ws, "ay_bn_train_fwd_bf16: null");
     hipStream_t st = S(stream);
     const int CP = (channels + 15) / 16, HW = h * w;
-    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
+    if (!ws_is_zero && hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
@@ -475,6 +475,22 @@ extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const flo
                        ch);
     AY_CHECK_LAUNCH("bn_apply_kernel");
     return AY_OK;
+}
+
+extern "C" int ay_bn_train_fwd_bf16(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                                    double* sums_ws, int batch, int channels, int h, int w, ay_stream_t stream) {
+    return bn_train_fwd(z, gamma, beta, running_mean, running_var, momentum, eps, leaky, skip, y, save_mean, save_invstd, sums_ws, false, batch,
+                        channels, h, w, stream);
+}
+// sums_ws holds zeros on entry (the caller clears the workspaces of ALL its layers with one memset per step instead of one per
+// layer and pass: 144 small fill launches per training step of Darknet-53)
+extern "C" int ay_bn_train_fwd_bf16_zeroed_ws(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                              float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean,
+                                              float* save_invstd, double* sums_ws_zeroed, int batch, int channels, int h, int w,
+                                              ay_stream_t stream) {
+    return bn_train_fwd(z, gamma, beta, running_mean, running_var, momentum, eps, leaky, skip, y, save_mean, save_invstd, sums_ws_zeroed, true,
+                        batch, channels, h, w, stream);
 }
 
 // the same layer when the producer of z already left (sum z, sum z^2) in sums_ws (ay_stem_train_fwd_stats_bf16): the apply pass alone
@@ -491,13 +507,13 @@ extern "C" int ay_bn_train_apply_bf16(const void* z, const float* gamma, const f
     return AY_OK;
 }
 
-extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
-                                        const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
-                                        int accumulate, int batch, int channels, int h, int w, ay_stream_t stream) {
+static int bn_train_bwd(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws, bool ws_is_zero,
+                        int accumulate, int batch, int channels, int h, int w, ay_stream_t stream) {
     AY_CHECK_ARG(dy && z && gamma && beta && save_mean && save_invstd && dz && dgamma && dbeta && sums_ws, "ay_bn_train_bwd_bf16: null");
     hipStream_t st = S(stream);
     const int CP = (channels + 15) / 16, HW = h * w;
-    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
+    if (!ws_is_zero && hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * channels, st) != hipSuccess) {
         set_error("memset failed");
         return AY_ERR_LAUNCH;
     }
@@ -510,6 +526,18 @@ extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const flo
                        accumulate);
     AY_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return AY_OK;
+}
+
+extern "C" int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
+                                        int accumulate, int batch, int channels, int h, int w, ay_stream_t stream) {
+    return bn_train_bwd(dy, z, gamma, beta, save_mean, save_invstd, leaky, dz, dgamma, dbeta, sums_ws, false, accumulate, batch, channels, h, w, stream);
+}
+extern "C" int ay_bn_train_bwd_bf16_acc_zeroed_ws(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                                  const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta,
+                                                  double* sums_ws_zeroed, int accumulate, int batch, int channels, int h, int w,
+                                                  ay_stream_t stream) {
+    return bn_train_bwd(dy, z, gamma, beta, save_mean, save_invstd, leaky, dz, dgamma, dbeta, sums_ws_zeroed, true, accumulate, batch, channels, h, w, stream);
 }
 
 extern "C" int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,

@@ -89,7 +89,7 @@ def train_forward(model, x, targets):
             if e["bn"]:
                 bn = m[1]
                 if training:
-                    check(L.ay_conv_fwd_f32(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(ones), ptr(zeros), None, ptr(z), st),
+                    check(L.ay_conv_fwd_f32_valu(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(ones), ptr(zeros), None, ptr(z), st),
                           "ay_conv_fwd_f32")
                     y = torch.empty_like(z)
                     mean = torch.empty(cout, device=dev, dtype=torch.float32)
@@ -105,14 +105,14 @@ def train_forward(model, x, targets):
                     check(L.ay_fold_bn(ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), None,
                                        C.c_float(bn.eps), ptr(scale), ptr(shift), cout, cout, st), "ay_fold_bn")
                     d.leaky = int(e["leaky"])
-                    check(L.ay_conv_fwd_f32(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(scale), ptr(shift), None, ptr(z), st),
+                    check(L.ay_conv_fwd_f32_valu(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(scale), ptr(shift), None, ptr(z), st),
                           "ay_conv_fwd_f32")
                     d.leaky = 0
                     y = z
                     rec.update(z=None, y=y, keep=(scale, shift))
             else:
                 bias = conv.bias.detach()
-                check(L.ay_conv_fwd_f32(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(ones), ptr(bias), None, ptr(z), st),
+                check(L.ay_conv_fwd_f32_valu(C.byref(d), ptr(src), e["cin"], 0, None, ptr(w), ptr(ones), ptr(bias), None, ptr(z), st),
                       "ay_conv_fwd_f32")
                 y = z
                 rec.update(z=z, y=y)

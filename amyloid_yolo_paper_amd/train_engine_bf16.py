@@ -248,6 +248,20 @@ def train_forward_bf16(model, x, targets):
             return o
         return v
 
+    # fp64 statistics workspaces of all BatchNorm layers, forward pass [0] and backward pass [1], as slices of ONE tensor cleared by
+    # one memset per step (the library's plain entry points clear theirs per call: 144 fill launches per step)
+    bn_layers = [j for j, g in enumerate(graph) if g["type"] == "convolutional" and g["bn"]]
+    off, bn_off = 0, {}
+    for j in bn_layers:
+        bn_off[j] = off
+        off += 4 * graph[j]["cout"]
+    bn_ws_flat = ctx.get("bn_ws_flat", (max(off, 1),), torch.float64)
+    bn_ws_flat.zero_()
+
+    def bn_ws(j, backward):
+        o = bn_off[j] + (2 * graph[j]["cout"] if backward else 0)
+        return bn_ws_flat[o:o + 2 * graph[j]["cout"]]
+
     row = 0
     sums_all = []
     nbt = []   # BatchNorm modules that ran: their num_batches_tracked counters are views of one flat tensor, bumped once per forward
@@ -292,7 +306,7 @@ def train_forward_bf16(model, x, targets):
             stats_done = False
             if stem_direct:
                 # forward + the layer's BatchNorm batch statistics in one kernel (the sums land in the layer's fp64 workspace)
-                ws = ctx.get(("ws", i), (2 * cout,), torch.float64)
+                ws = bn_ws(i, False)
                 nws = L.ay_stem_train_stats_workspace_bytes()
                 sws = ctx.buf.get("stem_stats_ws")
                 if sws is None or sws.numel() < nws:
@@ -308,13 +322,13 @@ def train_forward_bf16(model, x, targets):
             y = blocked(("y", i), cout, hout, pad=32)
             mean = ctx.get(("mean", i), (cout,), torch.float32)
             invstd = ctx.get(("invstd", i), (cout,), torch.float32)
-            ws = ctx.get(("ws", i), (2 * cout,), torch.float64)
-            check((L.ay_bn_train_apply_bf16 if stats_done else L.ay_bn_train_fwd_bf16)(
+            ws = bn_ws(i, False)
+            check((L.ay_bn_train_apply_bf16 if stats_done else L.ay_bn_train_fwd_bf16_zeroed_ws)(
                 ptr(z), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), C.c_float(bn.momentum),
                 C.c_float(bn.eps), int(e["leaky"]), ptr(skip), ptr(y), ptr(mean), ptr(invstd), ptr(ws), B, cout, hout, hout, st),
                 "ay_bn_train_fwd_bf16")
             nbt.append(bn)
-            rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, ws=ws)
+            rec.update(z=z, mean=mean, invstd=invstd, fused=fuse, ws=bn_ws(i, True))
             stt.conv[i] = rec
             if fuse:
                 val[i] = None          # never materialised: only the following shortcut uses it
@@ -500,7 +514,7 @@ def train_backward_bf16(model, stt, grad_scale=None):
                 dy = dval.pop(i)
             bn = m[1]
             dz = pool.get(tuple(rec["z"].shape))
-            check(L.ay_bn_train_bwd_bf16_acc(ptr(dy), ptr(rec["z"]), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(rec["mean"]), ptr(rec["invstd"]),
+            check(L.ay_bn_train_bwd_bf16_acc_zeroed_ws(ptr(dy), ptr(rec["z"]), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(rec["mean"]), ptr(rec["invstd"]),
                                              int(e["leaky"]), ptr(dz), ptr(bn.weight.grad), ptr(bn.bias.grad), ptr(rec["ws"]), 1, B, cout, hout, hout, st),
                   "ay_bn_train_bwd_bf16")
             if rec.get("fused"):

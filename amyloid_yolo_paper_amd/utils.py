@@ -172,17 +172,17 @@ def nms_device(pred_dev, conf_thres, nms_thres, max_det, slot=0):
 
 
 def graph_replay(graph):
-    """Replay a captured `torch.cuda.CUDAGraph` of library calls and FENCE it: an event recorded on the current stream behind the
-    replay, waited for by that same stream.  On ROCm 7.2 / PyTorch 2.10 work launched into a stream after `hipGraphLaunch` (and
-    stream / device synchronisation) does not wait for the graph's last node; an event recorded on the stream does.  Without the
-    fence the next step overlaps the tail of the replay -- the persistent kernels assume a launch starts after its predecessor
-    on the stream has drained (arena reuse, per-launch counter sets) -- which gave inconsistent detections and, with dynamic item
-    dealing, a GPU memory fault."""
+    """Replay a captured `torch.cuda.CUDAGraph` of library calls on the current stream, followed by the library's stream fence
+    (`ay_stream_fence`: an event owned by the library, recorded on the stream and waited for by the same stream; no host wait).
+
+    Round 2 attributed inconsistent replays to the runtime ("launches and stream / device synchronisation after hipGraphLaunch do
+    not wait for the graph").  Round 3 tested that claim in isolation (scripts/micro/graph_sync.hip, graph_coherence.hip: every
+    wait covers a replayed graph, and a kernel launched behind a replay sees all of its writes) and re-ran the unfenced test on the
+    current tree (static and dynamic item dealing, 4 of 4 runs equal to the eager step): the claim is withdrawn, the round-2 failures
+    are not reproduced (DESIGN.md section 4.1 keeps the record).  The fence stays as a stream-ordered no-op guard, now inside the
+    library instead of this helper."""
     graph.replay()
-    ev = torch.cuda.Event()
-    ev.record()
-    torch.cuda.current_stream().wait_event(ev)
-    return ev
+    check(_lib.lib().ay_stream_fence(_lib.stream_ptr()), "ay_stream_fence")
 
 
 def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.4):

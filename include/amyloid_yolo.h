@@ -153,6 +153,12 @@ int ay_nchw_f32_to_blocked_f16(const float* src, void* dst, int batch, int c, in
 int ay_conv_fwd_f32(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
                     const float* w_oihw, const float* scale, const float* shift, const float* residual,
                     float* out, ay_stream_t stream);
+/* The same block restricted to the VALU kernel (one fmaf chain per output in (ci, kh, kw) order; no matrix cores): the fp32
+ * training engine's forward, whose gradients are pinned element-wise by the reference's training fixtures on that summation
+ * order.  ay_conv_fwd_f32 itself runs the cfg format's shapes on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int ay_conv_fwd_f32_valu(const ay_conv_desc* d, const float* src1, int cin1, int up1, const float* src2,
+                    const float* w_oihw, const float* scale, const float* shift, const float* residual,
+                    float* out, ay_stream_t stream);
 
 /* ---- YOLO head decode: models.py:127-172 ------------------------------------------------------- */
 /* head: blocked f32 [B][cpad/16][G][G][16], cpad = A*(5+C) rounded up to 32 (layout=1) or nchw f32 [B][A*(5+C)][G][G] (layout=0).
@@ -288,6 +294,15 @@ int ay_bn_train_bwd_bf16(const void* dy, const void* z, const float* gamma, cons
 int ay_bn_train_bwd_bf16_acc(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
                              const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws,
                              int accumulate, int batch, int channels, int h, int w, ay_stream_t stream);
+/* The two BatchNorm calls for a caller that has CLEARED sums_ws itself (fp64 zeros on entry): a training step of Darknet-53
+ * zeroes the workspaces of all 72 layers and both passes with one memset instead of 144 small fill launches.  Otherwise
+ * identical to ay_bn_train_fwd_bf16 / ay_bn_train_bwd_bf16_acc (models.py:43 train-mode semantics and its backward). */
+int ay_bn_train_fwd_bf16_zeroed_ws(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, int leaky, const void* skip, void* y, float* save_mean, float* save_invstd,
+                                   double* sums_ws_zeroed, int batch, int channels, int h, int w, ay_stream_t stream);
+int ay_bn_train_bwd_bf16_acc_zeroed_ws(const void* dy, const void* z, const float* gamma, const float* beta, const float* save_mean,
+                                       const float* save_invstd, int leaky, void* dz, float* dgamma, float* dbeta, double* sums_ws_zeroed,
+                                       int accumulate, int batch, int channels, int h, int w, ay_stream_t stream);
 int ay_accumulate_bf16(void* dst, const void* src, size_t n_elems, ay_stream_t stream);
 /* route / nearest-upsample backward on blocked tensors (channel counts multiples of 16) */
 int ay_slice_accumulate_bf16(const void* dout, void* dsrc, int batch, int csrc, int ctotal, int c0, int h, int w, int up,
@@ -409,6 +424,17 @@ int ay_plan_profile_end(ay_plan* plan, float* op_ms_sum /* n_ops */, int* n_forw
 /* one forward with a HIP event pair around every op on `stream`; synchronises the stream and fills op_ms[n_ops] */
 int ay_plan_forward_timed(const ay_plan* plan, const float* x_nchw, void* workspace, float* out_rows, float* op_ms,
                           ay_stream_t stream);
+
+/* Replaying a captured HIP graph of these calls.  Every entry point is plain stream work (no allocation, no host copy, no
+ * symbol access inside a call), so a stream capture of a step (ay_plan_forward + ay_nms_merge ...) replays like any other
+ * graph; scripts/micro/graph_sync.hip and graph_coherence.hip show that on this runtime every wait covers a replayed graph and
+ * a kernel launched behind a replay sees its writes.  The persistent kernels do rely on stream order between launches (a
+ * launch hands its work-counter set back zeroed for a later launch on that stream, the plan's arena reuses a block once its
+ * last reader has been issued): replay a graph on ONE stream at a time and do not run other library work on the capture
+ * stream concurrently.  ay_stream_fence records a library-owned event on `stream` and makes the stream wait for it -- a
+ * stream-ordered no-op on a healthy runtime that utils.graph_replay() places behind every replay: round 2 saw unfenced
+ * replays return inconsistent steps on one pool host and fenced ones never (not reproduced since). */
+int ay_stream_fence(ay_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -77,13 +77,19 @@ def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):
     """One detection step (native plan forward + decode + merge-NMS) captured as a HIP graph (torch.cuda.CUDAGraph on a side
     stream), replayed after interleaved eager steps on other inputs: same bytes as the eager step on the same input.
 
-    The replay is fenced with `utils.graph_replay` (an event recorded behind the replay, waited for by the same stream).  That
-    fence is the root cause found in round 2: on this ROCm 7.2 / PyTorch 2.10 build, work launched into a
-    stream after `hipGraphLaunch` -- and `hipStreamSynchronize` / `hipDeviceSynchronize` -- do NOT wait for the graph's last node,
-    an event recorded on the stream does.  Unfenced, the next eager step overlapped the tail of the replay: 9 of 10 runs returned
-    an inconsistent step (static item dealing) or ended in a GPU memory fault (dynamic dealing: two launches alive on the same
-    arena and counter sets); fenced, 12 of 12 runs matched (3 with static, 9 with dynamic dealing).  AY_TEST_GRAPH_WAIT selects the other waits that
-    were compared (devsync / streamsync fail, tolist / event / waitevent pass) -- only for diagnosis, with AY_DYNAMIC=0."""
+    History.  Round 1 saw a GPU memory fault in this scenario; round 2 hardened what a launch carries outside a graph (per-stream
+    work-counter sets with clamped item ids, persistent NMS result buffers, no allocation inside a captured region, NMS keys
+    bounded), then measured 9 of 10 UNFENCED replays inconsistent or faulting and 12 of 12 fenced ones correct, and attributed
+    that to the runtime ("launches and stream / device synchronisation after hipGraphLaunch do not wait for the graph's last
+    node").  Round 3 tested the attribution in isolation and withdrew it: scripts/micro/graph_sync.hip (a captured kernel that
+    spins 40 ms and sets a flag last: hipStreamSynchronize, hipDeviceSynchronize, an event and a following kernel ALL see the flag,
+    60 of 60 observations, null / blocking / non-blocking streams, capture on a side stream) and graph_coherence.hip (a kernel
+    launched behind a replay reads every word the graph wrote, 0 stale reads in 64 runs); and this test with
+    AY_TEST_GRAPH_WAIT=devsync -- the variant that failed 8 of 8 times in round 2 -- passed 4 of 4 times on the current tree
+    (static and dynamic item dealing).  The round-2 failures are not reproduced; nothing in the kernels or in the runtime is
+    known to be wrong.  The replay here goes through `utils.graph_replay` = replay + `ay_stream_fence` (a library-owned event
+    recorded on the stream and waited for by the same stream: a stream-ordered no-op), the supported way to replay a step.
+    AY_TEST_GRAPH_WAIT selects the bare waits (devsync / streamsync / tolist / event / waitevent) for diagnosis."""
     from amyloid_yolo_paper_amd.utils import nms_device
     dev = torch.device("cuda", 0)
     m, _ = build_models(3, tmp_cfg_dir, dev, "bf16")

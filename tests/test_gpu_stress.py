@@ -41,7 +41,7 @@ def test_stress_2048_forward_nms(tmp_path):
     cfg = cfg_gen.write_cfg(Cc, str(tmp_path))
     params = synth.synth_params(parse_config.parse_model_config(cfg), seed=7)
     models = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp16"):
         m = Darknet(cfg, img_size=S, precision=prec)
         sd = m.state_dict()
         for i, p in params.items():
@@ -62,6 +62,13 @@ def test_stress_2048_forward_nms(tmp_path):
     scale = np.maximum(1.0, out32[..., 2:4].numpy().max(-1, keepdims=True))
     rel = np.abs(out16[..., :4].numpy() - out32[..., :4].numpy()) / scale
     assert np.quantile(rel, 0.999) <= 5e-2, float(np.quantile(rel, 0.999))
+    # the half-precision storage type (configs[4] "fp16 MFMA path"): the same bars divided by 8, the ratio of the rounding steps
+    outh = models["fp16"](x)
+    assert bool(torch.isfinite(outh).all())
+    dh = (outh[..., 4:] - out32[..., 4:]).abs().numpy()
+    assert np.quantile(dh, 0.99) <= 2.5e-3 and dh.max() <= 0.15 / 8, (float(np.quantile(dh, 0.99)), float(dh.max()))
+    relh = np.abs(outh[..., :4].numpy() - out32[..., :4].numpy()) / scale
+    assert np.quantile(relh, 0.999) <= 6.25e-3, float(np.quantile(relh, 0.999))
     # merge-NMS over all 258 048 rows: threshold chosen so that at least 500 candidates go in
     conf = out32[0, :, 4].numpy()
     thr = float(min(0.5, np.sort(conf)[-600]))
@@ -149,3 +156,92 @@ def test_stress_nms_over_65536_candidates():
     got = res[0].cpu().numpy()
     err = np.abs(got - o_rows[0]) / np.maximum(1.0, np.abs(o_rows[0]))
     assert err.max() <= 1e-4, float(err.max())
+
+
+def test_configs4_as_one_workload(tmp_cfg_dir):
+    """BASELINE.json configs[4] end to end on the 16-bit product path: 2048x2048 crops, 500 synthetic boxes per tile, GIoU box
+    loss, per-image merge-NMS, the half-precision MFMA path for detection (reference pieces: utils/utils.py:276-330 targets,
+    models.py:174-222 loss -- the GIoU term is this library's addition, pinned by tests/golden/giou_kat.json --,
+    utils/utils.py:235-273 NMS).
+
+    Full size (B=2 x 2048^2, 1 000 targets) -- properties: three optimiser steps of the bf16 training path (train-mode BN, fused
+    target assignment + GIoU loss, backward, flat Adam) stay finite and reduce the loss, the step's HBM peak stays bounded;
+    then a detection pass of the TRAINED weights on the fp16 inference path with merge-NMS over the 258 048 rows per tile: finite,
+    every kept index a candidate, and the two 16-bit storage types agree on the decoded rows at the level their rounding allows.
+    Oracle comparison of the same step at S=256 with 500 boxes per tile (the coarse grids are saturated: every cell holds several
+    targets, last writer wins): teacher-forced against the CPU oracle with box_loss="giou" -- forward per layer within one bf16
+    ulp, loss 1e-4, all 222 parameter gradients within u * sqrt(2L+1)."""
+    from amyloid_yolo_paper_amd.parallel import FlatAdam, FlatGradReducer
+    from amyloid_yolo_paper_amd.utils import weights_init_normal
+    from test_gpu_train_bf16 import check_step_against_oracle
+    dev = torch.device("cuda", 0)
+    Cc = 3
+    cfg = cfg_gen.write_cfg(Cc, tmp_cfg_dir)
+    defs = parse_config.parse_model_config(cfg)
+
+    # ---- (1) the oracle-pinned step: S = 256, 500 boxes per tile, GIoU
+    wpath = os.path.join(tmp_cfg_dir, f"synth_c{Cc}.weights")
+    if not os.path.exists(wpath):
+        synth.write_darknet_weights(wpath, defs, synth.synth_params(defs, seed=7), seen=0)
+    x = torch.from_numpy(synth.synth_tiles(2, 256, 30))
+    tg = torch.from_numpy(dense_targets(2, Cc, 500, 91))
+    m_small, l_small = check_step_against_oracle(cfg, defs, wpath, x, tg, box_loss="giou")
+    assert np.isfinite(l_small)
+    del m_small
+    torch.cuda.empty_cache()
+
+    # ---- (2) full size
+    B, S = 2, 2048
+    torch.manual_seed(4321)
+    model = Darknet(cfg, img_size=S, precision="bf16").to(dev)
+    model.apply(weights_init_normal)
+    model.box_loss = "giou"
+    model.train()
+    model.collect_metrics = False
+    red = FlatGradReducer(model.parameters(), n_buckets=4).attach(model)
+    opt = FlatAdam(red, lr=1e-4)   # (Adam moves every weight by lr per step whatever the gradient: at the default 1e-3 three steps from
+                                   # a random init leave eval-mode activations ~2000x and exp(tw) = inf on ANY path, the fp32 one included)
+    x = torch.from_numpy(synth.synth_tiles(B, S, start=7)).to(dev)
+    tg = torch.from_numpy(dense_targets(B, Cc, 500, 92)).to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    losses = []
+    for _ in range(3):
+        red.begin()
+        loss, _ = model.train_step_device(x, tg)
+        loss.backward()
+        red.all_reduce(average=False)
+        opt.step()
+        red.zero()
+        losses.append(float(loss.item()))
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    print(f"configs[4] B={B} S={S}, 500 boxes/tile, GIoU: loss {losses}, peak HBM {peak:.1f} GB")
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert peak < 30.0, peak            # the same pixels as B=8 at 1024^2 (configs[2] at B=32 peaks at 41 GB)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model._train_ctx = {}
+    del model, red, opt
+    torch.cuda.empty_cache()
+    outs = {}
+    for prec in ("fp16", "bf16"):
+        det = Darknet(cfg, img_size=S, precision=prec).to(dev)
+        det.load_state_dict(sd)
+        det.eval()
+        outs[prec] = det.forward_device(x).clone()
+        assert bool(torch.isfinite(outs[prec]).all()), prec
+        del det
+    o16 = outs["fp16"]
+    assert o16.shape == (B, 258048, 5 + Cc)
+    d = (o16[..., 4:] - outs["bf16"][..., 4:]).abs()
+    assert float(torch.quantile(d.flatten()[::97].float(), 0.99)) <= 2e-2, "the two 16-bit storage types disagree beyond bf16 rounding"
+    conf = o16[..., 4].flatten()
+    thr = float(min(0.5, torch.sort(conf).values[-1200]))    # at least 500 candidates per batch go into NMS
+    res = ay.non_max_suppression(o16.clone(), thr, 0.4)
+    for b in range(B):
+        n = 0 if res[b] is None else res[b].shape[0]
+        assert n == len(res.keep_idx[b]) and n <= int(res.cand_count[b])
+        if n:
+            assert bool(torch.isfinite(res[b]).all())
+            kept_conf = o16[b, torch.from_numpy(res.keep_idx[b]).to(dev), 4]
+            assert bool((kept_conf >= thr).all())                     # every kept index is a candidate row
+            assert len(set(res.keep_idx[b].tolist())) == n             # and no row is kept twice
+    assert sum(int(c) for c in res.cand_count) >= 500

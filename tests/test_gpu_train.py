@@ -263,6 +263,51 @@ def test_train_loop_checkpoint_and_eval(tmp_path, tmp_cfg_dir, precision, box_lo
     assert res is None or len(res) == 5
 
 
+def test_train_multiscale_on_the_gpu(tmp_path, tmp_cfg_dir):
+    """train() with the reference's DEFAULT multi-scale schedule (utils/datasets.py:78-79,131-133: every tenth batch a new side
+    from [S - 96, S + 96] in steps of 32; train.py:40 turns it on even when the flag is passed as a string): the bf16 engine keeps
+    a per-(batch, size) context, so a change of size mid-run must re-plan activations, statistics buffers and canvases.  12
+    batches at base size 160: at least two different sizes are trained on, every loss is finite, the checkpoint loads."""
+    import random
+    from PIL import Image
+    from amyloid_yolo_paper_amd.train import train
+    rng = np.random.Generator(np.random.PCG64(19))
+    img_dir, lab_dir = tmp_path / "images", tmp_path / "labels"
+    img_dir.mkdir()
+    lab_dir.mkdir()
+    paths = []
+    for i in range(8):
+        p = img_dir / f"t{i}.png"
+        Image.fromarray(synth.synth_tile(70 + i, 160)).save(p)
+        rows = [(int(rng.integers(0, 2)), *rng.uniform(0.2, 0.8, 2), *rng.uniform(0.1, 0.4, 2)) for _ in range(int(rng.integers(1, 4)))]
+        (lab_dir / f"t{i}.txt").write_text("\n".join("%d %.6f %.6f %.6f %.6f" % r for r in rows) + "\n")
+        paths.append(str(p))
+    (tmp_path / "train.txt").write_text("\n".join(paths) + "\n")
+    (tmp_path / "classes.names").write_text("CAA\nCored\n")
+    (tmp_path / "custom.data").write_text(f"classes= 2\ntrain={tmp_path}/train.txt\nvalid={tmp_path}/none.txt\nnames={tmp_path}/classes.names\n")
+    cfg = cfg_gen.write_cfg(2, tmp_cfg_dir)
+    random.seed(3)   # the schedule draws from Python's global generator, like the reference
+    sizes = []
+    from amyloid_yolo_paper_amd import train_engine_bf16 as eng
+    real = eng._context
+
+    def spy(model, B, S, dev):
+        sizes.append(S)
+        return real(model, B, S, dev)
+
+    eng._context = spy
+    try:
+        model, hist = train(epochs=3, batch_size=2, gradient_accumulations=2, model_def=cfg, data_config=str(tmp_path / "custom.data"),
+                            n_cpu=0, img_size=160, multiscale_training="True", checkpoint_dir=str(tmp_path / "ckpt"), precision="bf16")
+    finally:
+        eng._context = real
+    assert len(hist) == 12 and all(np.isfinite(hist)), hist
+    seen = sorted(set(sizes))
+    assert len(seen) >= 2 and all(64 <= s <= 256 and s % 32 == 0 for s in seen), seen
+    assert len(model._train_ctx) <= 2                      # the engine keeps the two most recent shapes
+    assert len(torch.load(str(tmp_path / "ckpt" / "yolov3_ckpt_2.pth"))) == 438
+
+
 _BT_NAMES = ["iou_scores", "class_mask", "obj_mask", "noobj_mask", "tx", "ty", "tw", "th", "tcls", "tconf"]
 
 

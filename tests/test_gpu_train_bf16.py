@@ -332,8 +332,6 @@ def test_bf16_train_step_vs_oracle(tmp_cfg_dir):
     (AY_CANVAS=0/1: identical loss, head gradients equal to 4e-8)."""
     import os
     from amyloid_yolo_paper_amd import cfg_gen, parse_config, synth
-    from amyloid_yolo_paper_amd.models import Darknet
-    from oracle.darknet_oracle import OracleDarknet
     C_, S, B = 3, 256, 4
     cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
     defs = parse_config.parse_model_config(cfg)
@@ -342,10 +340,31 @@ def test_bf16_train_step_vs_oracle(tmp_cfg_dir):
         synth.write_darknet_weights(wpath, defs, synth.synth_params(defs, seed=7), seen=0)
     x = torch.from_numpy(synth.synth_tiles(B, S, 10))
     tg = torch.from_numpy(synth.synth_targets(B, C_, seed=21, max_per_tile=6, min_per_tile=3, wh_range=(0.05, 0.4), grid=S // 8))
+    m, l16 = check_step_against_oracle(cfg, defs, wpath, x, tg)
 
+    # property (not a comparison): 8 Adam steps on the fixed batch reduce the loss
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.step()
+    opt.zero_grad()
+    for _ in range(7):
+        loss, _ = m(x, tg)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    e16 = float(loss.item())
+    assert np.isfinite(e16) and e16 < 0.75 * l16, (l16, e16)
+
+
+def check_step_against_oracle(cfg, defs, wpath, x, tg, box_loss="mse"):
+    """One bf16 training step of the HIP path on (x, tg), teacher-forced against the CPU oracle (see
+    test_bf16_train_step_vs_oracle for the bounds).  Returns (model with .grad filled, loss)."""
+    import os
+    from amyloid_yolo_paper_amd.models import Darknet
+    from oracle.darknet_oracle import OracleDarknet
     # ---- HIP step; the activations it stored
     m = Darknet(cfg, precision="bf16").to("cuda")
     m.load_darknet_weights(wpath)
+    m.box_loss = box_loss
     m.train()
     loss, out = m(x, tg)
     stt = loss.grad_fn.stt
@@ -364,6 +383,7 @@ def test_bf16_train_step_vs_oracle(tmp_cfg_dir):
     # ---- oracle at the same forward point
     o = OracleDarknet(cfg)
     o.load_darknet_weights(wpath)
+    o.box_loss = box_loss
     o.require_grad()
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     lo, _ = o.forward(x, tg, mode="bf16_train", train_bn=True, forced=forced)
@@ -407,15 +427,4 @@ def test_bf16_train_step_vs_oracle(tmp_cfg_dir):
         for got, ref in ((bn.running_mean, o.params[i]["mean"]), (bn.running_var, o.params[i]["var"])):
             ref = ref.detach()
             assert float((got.detach().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6, i
-
-    # property (not a comparison): 8 Adam steps on the fixed batch reduce the loss
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-    opt.step()
-    opt.zero_grad()
-    for _ in range(7):
-        loss, _ = m(x, tg)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-    e16 = float(loss.item())
-    assert np.isfinite(e16) and e16 < 0.75 * l16, (l16, e16)
+    return m, l16
