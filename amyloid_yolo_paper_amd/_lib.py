@@ -121,6 +121,8 @@ _SIGS = {
     "ay_blocked_f16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_nchw_f32_to_blocked_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ay_stream_fence": (_I, [_P]),
+    "ay_merge_detections_max_rows": (_I, []),
+    "ay_merge_detections": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "ay_nms_merge": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 

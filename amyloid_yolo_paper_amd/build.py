@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libamyloid_yolo_hip.so")
-SOURCES = ["ay_layout.hip", "ay_conv_bf16.hip", "ay_conv3x3_m16.hip", "ay_conv_f32.hip", "ay_conv_f32_mfma.hip", "ay_yolo.hip", "ay_nms.hip", "ay_train_f32.hip", "ay_stem_fused.hip", "ay_stem_train.hip", "ay_train_bf16.hip", "ay_wgrad_bf16.hip", "ay_ingest.hip", "ay_resblock_bf16.hip", "ay_stats.hip", "ay_plan.hip"]
+SOURCES = ["ay_layout.hip", "ay_conv_bf16.hip", "ay_conv3x3_m16.hip", "ay_conv_f32.hip", "ay_conv_f32_mfma.hip", "ay_yolo.hip", "ay_nms.hip", "ay_train_f32.hip", "ay_stem_fused.hip", "ay_stem_train.hip", "ay_train_bf16.hip", "ay_wgrad_bf16.hip", "ay_ingest.hip", "ay_resblock_bf16.hip", "ay_stats.hip", "ay_merge.hip", "ay_plan.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 if os.environ.get("AY_PHASE_CLOCK"):  # instrumented build: in-kernel phase clock of the ring convolution (AY_DBG=8 at run time)
     FLAGS.append("-DAY_PHASE_CLOCK")

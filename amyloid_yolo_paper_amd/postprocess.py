@@ -10,8 +10,11 @@ union of the two rectangles; confidences merge by ``min``; only classes 0 and 1 
 iteration order of a Python ``set`` of float tuples, an entry merged in a pass is not used again in that pass, and passes
 repeat until nothing changes.  The output rows are in that set's iteration order (callers treat them as a set).
 
-This is host code by nature (a few hundred boxes per tile, data-dependent fixed point); it is not a GPU kernel and does
-not touch the device."""
+``merge_detections`` is the host form, identical to the reference row for row INCLUDING the order CPython's set gives them.
+``merge_detections_device`` runs the same algorithm on the GPU for a whole batch (``ay_merge_detections``: one wavefront per
+image) with the pair order made explicit (rows in input order, merged rows appended): the same rows as the reference whenever
+the clusters are pairs, the reference's algorithm under that order for chains of merges (whose edges depend on the order
+through the one-pixel shrink per merge)."""
 import torch
 
 
@@ -58,3 +61,21 @@ def merge_detections(detections):
                     removed.add(ej)
                     changed = True
     return torch.as_tensor([list(e) for e in entries])
+
+
+def merge_detections_device(rows, count):
+    """``rows`` [B, max_rows, 7] float32 CUDA tensor of (x1, y1, x2, y2, conf, cls_conf, cls_pred), ``count`` [B] int32 valid rows per
+    image (what ``utils.nms_device`` returns, after rescaling) -> (merged rows [B, max_rows, 7], merged count [B]) on the device,
+    no host synchronisation."""
+    from . import _lib
+    L = _lib.lib()
+    assert rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 3 and rows.shape[2] == 7 and rows.is_contiguous()
+    B, M, _ = rows.shape
+    if M > L.ay_merge_detections_max_rows():
+        raise _lib.AyError(f"merge_detections_device: {M} rows per image (at most {L.ay_merge_detections_max_rows()})")
+    count = count.to(device=rows.device, dtype=torch.int32).contiguous()
+    out = torch.empty_like(rows)
+    out_count = torch.empty_like(count)
+    _lib.check(L.ay_merge_detections(_lib.ptr(rows), _lib.ptr(count), B, M, _lib.ptr(out), _lib.ptr(out_count), _lib.stream_ptr()),
+               "ay_merge_detections")
+    return out, out_count

@@ -28,6 +28,7 @@ def parse():
                     help="infer: tiles/s of the inference hot path (headline); train: imgs/s of the training step (configs[2]/[3])")
     ap.add_argument("--train_batch", type=int, default=32)
     ap.add_argument("--train_size", type=int, default=416, help="training tile side (reference default train.py:36)")
+    ap.add_argument("--no_other_dtype", action="store_true", help="default mode: skip the timing of the other 16-bit storage type")
     ap.add_argument("--no_train_leg", action="store_true", help="default mode: skip the appended training measurement (configs[2])")
     ap.add_argument("--no_fp32_leg", action="store_true", help="default mode: skip the appended fp32 parity-path measurement")
     ap.add_argument("--leg_train_size", type=int, default=1024, help="tile side of the appended training measurement (configs[2])")
@@ -207,6 +208,32 @@ def main():
 
     rows, keep, count, cand = res
     cnt, cnd = count.cpu().numpy(), cand.cpu().numpy()
+    # the other 16-bit storage type on the same workload, same protocol (own warm-up, barrier + synchronize around the same number
+    # of steps): reported beside the headline, never in place of it
+    other = "bf16" if a.dtype == "fp16" else "fp16"
+    other_line = None
+    if not a.no_other_dtype:
+        main_model, model = model, make_model(other)
+        slot_free[0] = slot_free[1] = None
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if USE_DIST:
+            dist.barrier()
+        torch.cuda.synchronize()
+        to0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if USE_DIST:
+            dist.barrier()
+        el_o = time.perf_counter() - to0
+        if USE_DIST:
+            t = torch.tensor([el_o], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_o = float(t.item())
+        other_line = {"dtype": other, "value": round(a.gpus * a.batch * a.steps / el_o, 2), "unit": "tiles/s", "ms_per_step": round(1e3 * el_o / a.steps, 3)}
+        other_model, model = model, main_model
     assert cnt.max() <= a.max_det, f"max_det {a.max_det} too small: {cnt.max()} cluster heads"
     raw_ok = bool(torch.isfinite(rows[0, : max(int(cnt[0]), 1)]).all())
     assert raw_ok, "non-finite detections"
@@ -222,6 +249,8 @@ def main():
                    "candidates_per_tile": round(float(cnd.mean()), 1), "detections_per_tile": round(float(cnt.mean()), 1),
                    "model_tflops": round(total_flops * a.steps * a.gpus / elapsed / 1e12, 1)},
     }
+    if other_line is not None:
+        result["other_dtype"] = other_line
     if rank == 0:
         if events:
             ms = sum(events)
@@ -237,16 +266,10 @@ def main():
                 "launches_per_step": launches // a.steps, "avg_launch_ms": round(ms / launches, 4),
                 "flops_per_launch": fam_flops / (launches // a.steps), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
             }
-        if not a.no_cpu_baseline and a.gpus == 1:
-            result["cpu_baseline"], ref_dets, ref_tiles = cpu_baseline(a, cfg, params)
-            result["parity"] = parity_vs_cpu(a, model, ref_dets, ref_tiles)     # the dtype that was timed
-            other = "bf16" if a.dtype == "fp16" else "fp16"
-            result["parity_" + other] = parity_vs_cpu(a, make_model(other), ref_dets, ref_tiles)  # the other 16-bit storage type, same tiles
     # ---- the rest of BASELINE.json's metric in the same line: "train imgs/sec @1/2/4/8 GPU" (configs[2]: B=32 per GPU, 1024^2), and the
-    # parity-grade fp32 path's tiles/s.  The inference model's buffers go first; RCCL comes up only now (an initialised communicator
-    # costs the inference step 3 %, see above) as a second process group next to the gloo one.
-    del model, x, res, rows, keep, count, cand
-    torch.cuda.empty_cache()
+    # parity-grade fp32 path's tiles/s.  All GPU legs first, the host-heavy CPU baseline + parity legs last.  RCCL comes up only now
+    # (an initialised communicator costs the inference step 3 %, see above) as a second process group next to the gloo one.
+    del x, res, rows, keep, count, cand
     if not a.no_train_leg:
         group = None
         try:
@@ -262,6 +285,10 @@ def main():
                 result["fp32_path"] = measure_fp32_path(a, cfg, params, dev)
             except Exception as exc:
                 result["fp32_path"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not a.no_cpu_baseline and a.gpus == 1:
+            result["cpu_baseline"], ref_dets, ref_tiles = cpu_baseline(a, cfg, params)
+            result["parity"] = parity_vs_cpu(a, model, ref_dets, ref_tiles)     # the dtype that was timed
+            result["parity_" + other] = parity_vs_cpu(a, other_model if other_line is not None else make_model(other), ref_dets, ref_tiles)  # the other 16-bit storage type, same tiles
         print(json.dumps(result), flush=True)
     if USE_DIST:
         dist.barrier()
@@ -437,7 +464,8 @@ def measure_fp32_path(a, cfg, params, dev):
             "what": "precision='fp32' (NCHW fp32 activations and filters, fp32 accumulate): the path that is bit-exact in NMS indices and within 1e-4 in "
                     "boxes against the reference on all five model fixtures (tests/test_gpu_parity.py::test_model_fp32_vs_reference_fixtures)",
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                         "kernel": m.fp32_kernel_name() if hasattr(m, "fp32_kernel_name") else "ay::conv_f32_kernel (VALU direct convolution)",
+                         "kernel": "ay::conv_f32_mfma_kernel<KS,STRIDE,KC,DUAL> (v_mfma_f32_32x32x2_f32: exact fp32 products and sums; 64 ch x 8x32 px per "
+                                   "workgroup, NCHW fp32 / OIHW fp32 as the reference lays them out; csrc/ay_conv_f32_mfma.hip)",
                          "what": "whole convolution stack of the fp32 path (395.65 GFLOP per 1024^2 tile) over its HIP-event time, against the exact-fp32 MFMA peak"}}
 
 

@@ -425,6 +425,16 @@ int ay_plan_profile_end(ay_plan* plan, float* op_ms_sum /* n_ops */, int* n_forw
 int ay_plan_forward_timed(const ay_plan* plan, const float* x_nchw, void* workspace, float* out_rows, float* op_ms,
                           ay_stream_t stream);
 
+/* ---- union-merge of overlapping same-class detections (core.py:366-423 mergeDetections, :326-364) ----------
+ * rows [batch][max_rows][7] = (x1, y1, x2, y2, conf, cls_conf, cls_pred) as ay_nms_merge leaves them (after rescaling), count[batch]
+ * valid rows per image -> rows_out [batch][max_rows][7], count_out[batch]: pairs of rows of class 0 or 1 whose truncated integer pixel
+ * rectangles share a pixel are replaced by the rectangle of the covered pixels (min of the confidences), pass after pass until
+ * nothing changes, exactly as the reference does -- with the pair order the reference leaves to a Python set made explicit: rows
+ * in input order, merged rows appended.  One wavefront per image, rows in LDS; max_rows <= ay_merge_detections_max_rows(). */
+int ay_merge_detections_max_rows(void);
+int ay_merge_detections(const float* rows, const int* count, int batch, int max_rows, float* rows_out, int* count_out,
+                        ay_stream_t stream);
+
 /* Replaying a captured HIP graph of these calls.  Every entry point is plain stream work (no allocation, no host copy, no
  * symbol access inside a call), so a stream capture of a step (ay_plan_forward + ay_nms_merge ...) replays like any other
  * graph; scripts/micro/graph_sync.hip and graph_coherence.hip show that on this runtime every wait covers a replayed graph and

@@ -281,3 +281,53 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
     p, r, ap = np.array(p), np.array(r), np.array(ap)
     f1 = 2 * p * r / (p + r + 1e-16)
     return p, r, ap, f1, unique_classes.astype("int32")
+
+
+def merge_detections_ordered(det):
+    """``mergeDetections`` (core.py:366-423, with ``combineIfOverlapping`` core.py:326-364) with the one thing the reference leaves
+    to CPython -- the iteration order of its set of row tuples -- made explicit: rows in input order, merged rows appended in
+    creation order.  Everything else as the reference has it: identical rows collapse (``set``); per pass all pairs i < j of the
+    pass's list; only classes 0 and 1; ``int()`` truncation of x1, y1, x2 - x1, y2 - y1; overlap = the pixel rectangles
+    [x, x+w) x [y, y+h) share a pixel; merged row = (left, top, last covered column, last covered row, min conf, min cls_conf,
+    label); skipped if that row is already in the set; ``removed`` is a set of row VALUES; passes until nothing changes.
+    det: float32 [n,7].  Returns float64 [m,7] in list order.  (The device kernel ay_merge_detections implements exactly this.)"""
+    rows, seen = [], set()
+    for r in np.asarray(det, np.float32).reshape(-1, 7).tolist():
+        t = tuple(r)
+        if t not in seen:
+            seen.add(t)
+            rows.append(t)
+    live = [True] * len(rows)
+    removed = set()
+    while True:
+        changed = False
+        limit = len(rows)
+        for i in range(limit):
+            for j in range(i + 1, limit):
+                ei, ej = rows[i], rows[j]
+                if not live[i] or not live[j]:
+                    continue
+                if not ((ei[6] == 1 == ej[6]) or (ei[6] == 0 == ej[6])):
+                    continue
+                if ei in removed or ej in removed:
+                    continue
+                xi, yi, wi, hi = int(ei[0]), int(ei[1]), int(ei[2] - ei[0]), int(ei[3] - ei[1])
+                xj, yj, wj, hj = int(ej[0]), int(ej[1]), int(ej[2] - ej[0]), int(ej[3] - ej[1])
+                if wi <= 0 or hi <= 0 or wj <= 0 or hj <= 0:
+                    continue
+                if min(xi + wi, xj + wj) <= max(xi, xj) or min(yi + hi, yj + hj) <= max(yi, yj):
+                    continue
+                left, top = min(xi, xj), min(yi, yj)
+                right, bottom = max(xi + wi, xj + wj) - 1, max(yi + hi, yj + hj) - 1
+                new = (left, top, right, bottom, min(ei[4], ej[4]), min(ei[5], ej[5]), ei[6])
+                if any(live[k] and rows[k] == new for k in range(len(rows))):
+                    continue
+                rows.append(new)
+                live.append(True)
+                live[i] = live[j] = False
+                removed.add(ei)
+                removed.add(ej)
+                changed = True
+        if not changed:
+            break
+    return np.asarray([rows[k] for k in range(len(rows)) if live[k]], np.float64).reshape(-1, 7)

@@ -755,6 +755,45 @@ def test_detect_region_equals_per_tile_detection(tmp_cfg_dir, dev):
         assert torch.equal(d, expect[(a, b_)])
 
 
+def test_merge_detections_device(golden_dir, dev):
+    """ay_merge_detections (SURVEY 8f N3 on the device: core.py:366-423 + 326-364, one wavefront per image) against
+    (a) the reference's own outputs as sets of rows on the fixture cases whose result does not depend on the set's iteration
+    order, and (b) bit for bit, rows AND order, the CPU restatement with the kernel's explicit pair order
+    (oracle.merge_detections_ordered) on the fixtures and on batches of clustered boxes with long merge chains, exact
+    duplicates, empty images and a full 1024-row image."""
+    from amyloid_yolo_paper_amd.postprocess import merge_detections_device
+    z = load(golden_dir, "merge_cases")
+    cases = dict(gc.merge_inputs())
+    rng = np.random.Generator(np.random.PCG64(123))
+    for k, (n, ncl, spread) in enumerate([(300, 12, 60.0), (1024, 40, 25.0), (64, 3, 5.0), (0, 1, 1.0)]):
+        centers = rng.uniform(50, 1450, (ncl, 2))
+        xy = centers[rng.integers(0, ncl, n)] + rng.normal(0, spread, (n, 2))
+        wh = rng.uniform(6, 90, (n, 2))
+        det = np.concatenate([xy, xy + wh, rng.uniform(0.5, 1, (n, 2)), rng.integers(0, 3, (n, 1))], 1).astype(np.float32)
+        if n >= 64:
+            det[5] = det[2]            # exact duplicates collapse like rows of a Python set
+            det[40] = det[2]
+        cases[f"clusters{k}"] = det
+    names = list(cases)
+    M = 1024
+    rows = torch.zeros(len(names), M, 7)
+    count = torch.zeros(len(names), dtype=torch.int32)
+    for b, name in enumerate(names):
+        d = cases[name]
+        rows[b, :len(d)] = torch.from_numpy(d)
+        count[b] = len(d)
+    out, out_count = merge_detections_device(rows.to(dev).contiguous(), count.to(dev))
+    out, out_count = out.cpu().numpy(), out_count.cpu().numpy()
+    for b, name in enumerate(names):
+        want = bo.merge_detections_ordered(cases[name])
+        got = out[b, :out_count[b]].astype(np.float64)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        np.testing.assert_array_equal(got, want, err_msg=name)
+        if name in z and name != "random40":
+            assert set(map(tuple, got.tolist())) == set(map(tuple, z[name].reshape(-1, 7).tolist())), name
+    assert out_count[names.index("clusters1")] < 1024 and out_count[names.index("clusters3")] == 0
+
+
 def test_giou_closed_form_vectors_hip(golden_dir):
     """ay_box_iou / ay_box_iou_pairwise in GIoU mode against the exact rationals of the published definition
     (tests/golden/giou_kat.json; the reference has no GIoU)."""
