@@ -5,9 +5,9 @@ set -e
 export TMPDIR=/tmp
 TAG=$1
 R=${ROUND:-r03}
-INF="--no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg"
+INF="--no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg --dtype ${AY_PROFILE_DTYPE:-bf16}"
 rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write
-# ---- inference (the timed dtype of bench.py's default line)
+# ---- inference (the timed dtype of bench.py's default line: bf16; AY_PROFILE_DTYPE=fp16 profiles the other one)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 5 --warmup 2 $INF > gpurun_out/bench_kt_$TAG.log 2>&1
 cp gpurun_out/prof_kt/*/*_kernel_stats.csv gpurun_out/${R}_bench_b64_kernel_stats_$TAG.csv
 python scripts/layer_times.py gpurun_out/prof_kt > gpurun_out/${R}_bench_b64_layer_times_$TAG.txt
