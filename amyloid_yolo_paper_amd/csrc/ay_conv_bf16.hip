@@ -792,10 +792,10 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
 // Data gradient of a 3x3 stride-2 convolution as four 2x2-window stride-1 convolutions over dz, one per parity class of the
 // output pixel: the ring kernel with KS = 2, classes riding in the channel-group index (class fastest, so the four classes of a
 // tile -- which interleave in the same 128-byte lines of dx -- run side by side)
-template <int BN, int WM, int WN, int NK>
+template <int BN, int WM, int WN, int NK, int TH = 8>
 static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w, const float* scale, const float* shift,
                            const void* residual, void* dx, int cin_pad, hipStream_t st) {
-    constexpr int TH = 8, TW = 32;
+    constexpr int TW = 32;
     ay_conv_desc dd = *d;
     dd.cin = d->cout_pad;     // reduction over dz's channel planes
     dd.cout = d->cin;
@@ -861,6 +861,14 @@ extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, cons
     hipStream_t st = S(stream);
     const int kin = d->cout_pad;
     if (cin_pad % 128 == 0 && kin % 32 == 0) return launch_dgrad_s2<128, 2, 4, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    // the narrow layers (32 / 64 channels of dx: the first two stride-2 layers) have one or two stages per item and are bound by the
+    // per-item cost of the ring kernel: 16x32-pixel items (half as many): 72.5 -> 72.0 ms per training step at B=32 / 1024^2
+    // (AY_S2_TH16=0: 8x32 items)
+    static const int th16 = getenv("AY_S2_TH16") ? atoi(getenv("AY_S2_TH16")) : 1;
+    if (th16 && d->hout >= 16) {
+        if (cin_pad % 128 != 0 && cin_pad % 64 == 0 && kin % 32 == 0) return launch_dgrad_s2<64, 1, 8, 2, 16>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+        if (cin_pad % 64 != 0 && kin % 32 == 0) return launch_dgrad_s2<32, 1, 8, 2, 16>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    }
     if (cin_pad % 64 == 0 && kin % 32 == 0) return launch_dgrad_s2<64, 1, 8, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
     if (kin % 64 == 0) return launch_dgrad_s2<32, 1, 8, 4>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
     return launch_dgrad_s2<32, 1, 8, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
