@@ -7,13 +7,14 @@ from amyloid_yolo_paper_amd import cfg_gen, synth, parse_config
 from amyloid_yolo_paper_amd.models import Darknet
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-B = 64 // R
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64 // R      # tiles per replica (default: a batch of 64 split R ways)
+PREC = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 dev = torch.device("cuda:0")
 cfg = cfg_gen.write_cfg(3, "/tmp/cfg_rs")
 models = []
 params = synth.synth_params(parse_config.parse_model_config(cfg), seed=7)
 for r in range(R):
-    m = Darknet(cfg, img_size=1024, precision="bf16")
+    m = Darknet(cfg, img_size=1024, precision=PREC)
     sd = m.state_dict()
     for i, p in params.items():
         for k, name in (("weight", f"conv_{i}.weight"), ("bias", f"conv_{i}.bias"), ("gamma", f"batch_norm_{i}.weight"),
@@ -38,4 +39,4 @@ for _ in range(K):
     step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"R={R} B/replica={B} AY_CUS={os.environ.get('AY_CUS')} ms/step(64 tiles)={dt*1e3:.2f} tiles/s={64/dt:.1f}")
+print(f"R={R} B/replica={B} {PREC} AY_CUS={os.environ.get('AY_CUS')} ms per {R * B} tiles={dt*1e3:.2f} tiles/s={R * B/dt:.1f}")
