@@ -28,7 +28,7 @@ for i in range(N):
 torch.cuda.synchronize()
 print("forward only: %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
 
-# the same forward captured as a HIP graph and replayed through the event fence (utils.graph_replay)
+# the same forward captured as a HIP graph and replayed through utils.graph_replay (replay + ay_stream_fence)
 from amyloid_yolo_paper_amd.utils import graph_replay
 side = torch.cuda.Stream(device=dev)
 side.wait_stream(torch.cuda.current_stream())
@@ -36,13 +36,11 @@ g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g, stream=side):
     model.forward_device(x, out_slot=0)
 torch.cuda.synchronize()
-for _ in range(3):
+for _ in range(4):
     graph_replay(g)
-ev = graph_replay(g)
-ev.synchronize()
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(N):
-    ev = graph_replay(g)
-ev.synchronize()
+    graph_replay(g)
 torch.cuda.synchronize()
 print("forward only, graph replay: %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
