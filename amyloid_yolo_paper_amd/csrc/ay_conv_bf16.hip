@@ -203,9 +203,12 @@ constexpr int DEAL_SETS = 64, DEAL_STREAMS = 16;
 __device__ unsigned g_deal[DEAL_STREAMS * DEAL_SETS][16];
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false,
-          typename DT = Bf16>
+          typename DT = Bf16, bool PAIR = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
     typedef typename DT::vec8 vec8;
+    // PAIR (2x2-window kernels only): the tile's BN "channels" are the two column-parity classes of BN / 2 real channels, side by side
+    // (ay_conv_common.h: pair_block); the channel-group index then carries the ROW parity in its low bit
+    static_assert(!PAIR || KS == 2, "class pairs: the parity-class data gradient");
     static_assert(!CANVAS || !CAT, "canvas tiling: single-source layers");
     // KS == 2: a 2x2 window with offsets {0, +1} (no padding on the low side) whose channel-group index carries an output pixel
     // parity class; see ConvArgs::w_class_stride
@@ -331,16 +334,21 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         ld_src = a.src + (size_t)b * ((a.cin - (CAT ? a.c1 : 0)) / 16) * in_plane;
         if constexpr (CAT) ld_src1 = a.src1 + (size_t)b * (a.c1 / 16) * in_plane1;
         const uint8_t* wbase = a.w;
-        if constexpr (UP2) {
+        if constexpr (PAIR) {   // classes (2 py, 2 py + 1): two consecutive filter images
+            wbase += (size_t)((cg & 1) * 2) * a.w_class_stride;
+            cg >>= 1;
+        } else if constexpr (UP2) {
             wbase += (size_t)(cg & 3) * a.w_class_stride;
             cg >>= 2;
         }
-        ld_w = wbase + (size_t)cg * BN * 16;
+        constexpr int BNR = PAIR ? BN / 2 : BN;   // real channels of the group
+        ld_w = wbase + (size_t)cg * BNR * 16;
         // lanes 0..BN/4-1 fetch 4 scales each, lanes 32..32+BN/4-1 the shifts: LDS image [scale | pad to 128][shift]
+        // (PAIR: tile channel t is real channel t % BNR of the group)
         if constexpr (SSP == 1)
-            ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BN + (lane & 31) * 4) : nullptr;
+            ld_ss = (lane & 31) < BN / 4 ? ((lane < 32 ? a.scale : a.shift) + (size_t)cg * BNR + ((lane & 31) * 4) % BNR) : nullptr;
         else  // 256 channels: lane l carries scales (piece NPIECE) / shifts (piece NPIECE + 1) 4l..4l+3
-            ld_ss = a.scale + (size_t)cg * BN + lane * 4;
+            ld_ss = a.scale + (size_t)cg * BNR + (lane * 4) % BNR;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             int off = -1, off1 = -1;
@@ -362,7 +370,12 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 const int qq = (i - PWP) * 8 + wave;   // filter piece; qq >= NK * W_PIECES: scale/shift or padding
                 const int u = qq * 64 + lane;          // unit inside the stage's filter image [kk][tap][half][BN]
                 const int r = u % BN, th = u / BN;
-                if (qq < NK * W_PIECES) off = (th * CP + r) * 16;
+                if (qq < NK * W_PIECES) {
+                    if constexpr (PAIR)   // rows BN/2.. of the tile: the second class's image, w_class_stride further on
+                        off = (th * CP + r % (BN / 2)) * 16 + (r / (BN / 2)) * (int)a.w_class_stride;
+                    else
+                        off = (th * CP + r) * 16;
+                }
             }
             src_off[i] = off;
             if constexpr (CAT) src_off1[i] = off1;
@@ -454,8 +467,11 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     while (true) {
         if (clk) tk0 = wall_clock64();
         int cg = item % a.n_cgroups;
-        const int cls = UP2 ? (cg & 3) : 0;
-        if constexpr (UP2) cg >>= 2;
+        const int cls = PAIR ? (cg & 1) * 2 : UP2 ? (cg & 3) : 0;
+        if constexpr (PAIR)
+            cg >>= 1;
+        else if constexpr (UP2)
+            cg >>= 2;
         const int pt = item / a.n_cgroups;
         const int b = pt / tiles_per_img;
         const int y0 = ((pt / a.tiles_x) % a.tiles_y) * TH, x0 = (pt % a.tiles_x) * TW;
@@ -481,7 +497,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             constexpr bool EARLY_RES = (MT * NT <= 4);  // 32 VGPRs of residual; larger wave tiles load it in the epilogue
-            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES, CANVAS, UP2>(a, rr, b, cg, wm, wn, c, hh, y0, x0, cls);
+            if (EARLY_RES && last_stage) residual_prefetch<BN, MT, NT, TW, HAS_RES, CANVAS, UP2, PAIR>(a, rr, b, cg, wm, wn, c, hh, y0, x0, cls);
 
             const uint8_t* L = lds + cur * BUF_BYTES;
             constexpr int NSTEP = NK * KK2;
@@ -541,7 +557,7 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         }
         int fetched = last;
         if (MAILBOX && tid == 0) fetched = fetch_id(mbox[(seq_c + D - 1) & 7]);  // id[c+D]; consumed after the epilogue
-        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS, UP2, DT>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
+        conv_epilogue<BN, MT, NT, TW, false, HAS_RES, (MT * NT > 4), 1, CANVAS, UP2, DT, PAIR>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0,
                                                                             reinterpret_cast<const float*>(lds + SS_BASE + par * SSR), cls);
         if (MAILBOX && tid == 0) {
             mbox[(seq_c + D) & 7] = fetched;
@@ -792,7 +808,7 @@ static int launch_ring1x1(const ay_conv_desc* d, const void* src1, int c1, const
 // Data gradient of a 3x3 stride-2 convolution as four 2x2-window stride-1 convolutions over dz, one per parity class of the
 // output pixel: the ring kernel with KS = 2, classes riding in the channel-group index (class fastest, so the four classes of a
 // tile -- which interleave in the same 128-byte lines of dx -- run side by side)
-template <int BN, int WM, int WN, int NK, int TH = 8>
+template <int BN, int WM, int WN, int NK, int TH = 8, bool PAIR = false>
 static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w, const float* scale, const float* shift,
                            const void* residual, void* dx, int cin_pad, hipStream_t st) {
     constexpr int TW = 32;
@@ -804,7 +820,9 @@ static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w,
     dd.ksize = 2, dd.stride = 1, dd.leaky = 0, dd.out_f32 = 0;
     ConvArgs a;
     fill_args(a, &dd, dz, w, scale, shift, residual, dx, TH, TW, BN);
-    a.n_cgroups = 4 * (cin_pad / BN);
+    // BN is the TILE width: with PAIR it holds the two column-parity classes of BN / 2 real channels, and an item's group index carries
+    // only the row parity
+    a.n_cgroups = PAIR ? 2 * (cin_pad / (BN / 2)) : 4 * (cin_pad / BN);
     a.w_class_stride = (unsigned)((size_t)(d->cout_pad / 16) * 4 * 2 * cin_pad * 16);
     const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
@@ -817,9 +835,9 @@ static int launch_dgrad_s2(const ay_conv_desc* d, const void* dz, const void* w,
     dim3 pgrid((unsigned)(8 * (per_xcd < cu_slots ? per_xcd : cu_slots))), block(512);
     constexpr int NBUF = ring_depth<2, 1, BN, TH, TW, NK>();
     if (residual)
-        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, true>), pgrid, block, 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, true, false, false, Bf16, PAIR>), pgrid, block, 0, st, a, (int)nblk);
     else
-        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, false>), pgrid, block, 0, st, a, (int)nblk);
+        hipLaunchKernelGGL((conv_bf16_ring_kernel<2, 1, BN, WM, WN, TH, TW, NK, NBUF, false, false, false, Bf16, PAIR>), pgrid, block, 0, st, a, (int)nblk);
     AY_CHECK_LAUNCH("conv_bf16_ring_kernel(dgrad s2)");
     return AY_OK;
 }
@@ -860,6 +878,16 @@ extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, cons
     AY_CHECK_ARG((long long)d->hin * d->win * 2 * cin_pad < (1ll << 31), "ay_conv_dgrad_s2_bf16: one image of dx exceeds 2 GiB");
     hipStream_t st = S(stream);
     const int kin = d->cout_pad;
+    // Class pairs (AY_S2_PAIR, default on): one workgroup computes BOTH column-parity classes of a row parity -- the tile's channels are
+    // the two classes side by side -- so that a wave stores neighbouring pixels in consecutive instructions (whole lines reach HBM).
+    static const int pair = getenv("AY_S2_PAIR") ? atoi(getenv("AY_S2_PAIR")) : 1;
+    if (pair && kin % 32 == 0) {
+        if (cin_pad % 128 == 0) return launch_dgrad_s2<256, 4, 2, 1, 8, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+        static const int pth16 = getenv("AY_S2_PAIR_TH16") ? atoi(getenv("AY_S2_PAIR_TH16")) : 1;   // 16x32-pixel items for the 32-channel layer
+        if (pth16 && d->hout >= 16 && cin_pad % 64 != 0) return launch_dgrad_s2<64, 1, 8, 2, 16, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+        if (cin_pad % 64 == 0) return launch_dgrad_s2<128, 2, 4, 2, 8, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+        return launch_dgrad_s2<64, 1, 8, 2, 8, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    }
     if (cin_pad % 128 == 0 && kin % 32 == 0) return launch_dgrad_s2<128, 2, 4, 2>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
     // the narrow layers (32 / 64 channels of dx: the first two stride-2 layers) have one or two stages per item and are bound by the
     // per-item cost of the ring kernel: 16x32-pixel items (half as many): 72.5 -> 72.0 ms per training step at B=32 / 1024^2

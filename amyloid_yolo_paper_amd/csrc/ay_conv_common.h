@@ -78,13 +78,29 @@ struct ResRegs {
     uint4 r[MT][NT][2];
 };
 
-template <int BN, int MT, int NT, int TW, bool HAS_RES, bool CANVAS = false, bool UP2 = false>
+// PAIR (with UP2): the workgroup's BN "channels" are the two column-parity classes (cls, cls + 1) of BN / 2 real channels each, side
+// by side: block blk of 32 tile channels = class cls + (blk * 32) / (BN / 2), real channels cg * (BN / 2) + (blk * 32) % (BN / 2) ...  A
+// wave then stores pixel (.., 2 ox) and pixel (.., 2 ox + 1) of a plane in consecutive instructions: whole lines leave the CU, where
+// one class per workgroup leaves 32-byte segments at a 64-byte stride that reach HBM at 1.25 instead of 4.3-5.5 TB/s
+// (scripts/micro/partial_line_stores.hip).
+template <int BN, bool PAIR>
+__device__ __forceinline__ void pair_block(int cg, int blk, int cls, int& ch_first, int& cls_out) {
+    if constexpr (PAIR) {
+        constexpr int HALF = BN / 2;
+        ch_first = cg * HALF + (blk * 32) % HALF;
+        cls_out = cls + (blk * 32) / HALF;
+    } else {
+        ch_first = cg * BN + blk * 32;
+        cls_out = cls;
+    }
+}
+
+template <int BN, int MT, int NT, int TW, bool HAS_RES, bool CANVAS = false, bool UP2 = false, bool PAIR = false>
 __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT, NT>& rr, int b, int cg, int wm, int wn, int c,
                                                   int hh, int y0, int x0, int cls = 0) {
     if constexpr (HAS_RES) {
         const int CP = a.cout_pad;
         const size_t out_plane_px = (size_t)a.hout * a.wout * (UP2 ? 4 : 1);
-        const int cbase = cg * BN + wm * MT * 32;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int p = (wn * NT + n) * 32 + c;
@@ -95,15 +111,18 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
             if constexpr (CANVAS) {
                 if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;  // any valid address
             }
-            const size_t pix = UP2 ? (size_t)(2 * oy + (cls >> 1)) * (2 * a.wout) + 2 * ox + (cls & 1) : (size_t)oy * a.wout + ox;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                int chf, clm;
+                pair_block<BN, PAIR>(cg, wm * MT + m, cls, chf, clm);
+                const size_t pix = UP2 ? (size_t)(2 * oy + (clm >> 1)) * (2 * a.wout) + 2 * ox + (clm & 1) : (size_t)oy * a.wout + ox;
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
-                    const int ch0 = cbase + m * 32 + qp * 16;
+                    const int ch0 = chf + qp * 16;
                     const size_t plane = (size_t)bb * (CP / 16) + (ch0 >> 4);
                     rr.r[m][n][qp] = *reinterpret_cast<const uint4*>(a.residual + (plane * out_plane_px + pix) * 32 + hh * 16);
                 }
+            }
         }
     }
 }
@@ -125,17 +144,19 @@ __device__ __forceinline__ void residual_prefetch(const ConvArgs& a, ResRegs<MT,
 // CANVAS: the tile lies on the canvas of ConvArgs::canvas_gx (a compile-time switch: as run-time branches the mapping code
 // cost the kernels that never use it SGPR spills -- the fused block went from 1.36 to 1.81 ms)
 template <int BN, int MT, int NT, int TW, bool OUT_F32, bool HAS_RES, bool RES_INLINE = false, int SS_MODE = 0, bool CANVAS = false,
-          bool UP2 = false, typename DT = Bf16>
+          bool UP2 = false, typename DT = Bf16, bool PAIR = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ResRegs<MT, NT>& rr, int b, int cg,
                                               int wm, int wn, int c, int hh, int y0, int x0, const float* ss_lds = nullptr, int cls = 0) {
     static_assert(!UP2 || (!CANVAS && !OUT_F32), "parity-class output: plain bf16 tiles");
+    static_assert(!PAIR || UP2, "class pairs exist for the parity-class output");
     const int CP = a.cout_pad;
     const size_t out_plane_px = (size_t)a.hout * a.wout * (UP2 ? 4 : 1);
     // pixel index of output (oy, ox) inside a plane
-    auto opix = [&](int oy, int ox) __attribute__((always_inline)) {
-        return UP2 ? (unsigned)(2 * oy + (cls >> 1)) * (unsigned)(2 * a.wout) + 2 * ox + (cls & 1) : (unsigned)oy * a.wout + ox;
+    auto opix = [&](int oy, int ox, int cl) __attribute__((always_inline)) {
+        return UP2 ? (unsigned)(2 * oy + (cl >> 1)) * (unsigned)(2 * a.wout) + 2 * ox + (cl & 1) : (unsigned)oy * a.wout + ox;
     };
-    const int cbase = cg * BN + wm * MT * 32;
+    // first real channel and parity class of this wave's m-th block of 32 tile channels (PAIR: see pair_block)
+    auto blk_of = [&](int m, int& chf, int& clm) __attribute__((always_inline)) { pair_block<BN, PAIR>(cg, wm * MT + m, cls, chf, clm); };
     const int lbase = wm * MT * 32;  // channel index inside the workgroup's BN channels
     constexpr int SHO = BN > 128 ? BN : 128;  // float offset of the shifts in the LDS scale/shift image
     const float slope = a.leaky ? 0.1f : 1.0f;
@@ -172,10 +193,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         if constexpr (CANVAS) {
             if (!canvas_px(a, y0 + p / TW, x0 + p % TW, bb, oy, ox)) bb = oy = ox = 0;
         }
-        const unsigned pix_off = opix(oy, ox) * 32u + hh * 16u + (unsigned)bb * img_bytes;
+        int chf, clm;
+        blk_of(m, chf, clm);
+        const unsigned pix_off = opix(oy, ox, clm) * 32u + hh * 16u + (unsigned)bb * img_bytes;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes);
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((chf + qp * 16) >> 4) * plane_bytes);
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, pix_off, so, 0);
             r[qp] = make_uint4(v[0], v[1], v[2], v[3]);
         }
@@ -190,13 +213,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         int oy = y0 + p / TW, ox = x0 + p % TW, bn = b;  // bn: the image of this lane's pixel (canvas mode: per lane)
         bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
         if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
-        const size_t pix = opix(oy, ox);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int t = n * MT + m;
+            int chf, clm;
+            blk_of(m, chf, clm);
+            const size_t pix = opix(oy, ox, clm);
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {  // quad pair (2qp, 2qp+1) -> 16-channel plane
-                const int ch0 = cbase + m * 32 + qp * 16;  // first channel of the plane
+                const int ch0 = chf + qp * 16;  // first channel of the plane
                 f32x2 v01, v23, w01, w23;                  // quad 2qp, quad 2qp+1
                 {
                     f32x4 s0, t0, s1, t1;
@@ -274,13 +299,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             int oy = y0 + p / TW, ox = x0 + p % TW, bn = 0;
             bool ok = (oy < a.hout) && (ox < a.wout) && !AY_DBGBIT(a, 4);
             if constexpr (CANVAS) ok = canvas_px(a, y0 + p / TW, x0 + p % TW, bn, oy, ox) && !AY_DBGBIT(a, 4);
-            const unsigned vo = ok ? opix(oy, ox) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                int chf, clm;
+                blk_of(m, chf, clm);
+                const unsigned vo = ok ? opix(oy, ox, clm) * 32u + hh * 16u + (unsigned)bn * img_bytes : 0x80000000u;
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp)
-                    __builtin_amdgcn_raw_buffer_store_b128(outv[n * MT + m][qp], orsrc,
-                                                           vo + (unsigned)((cbase + m * 32 + qp * 16) >> 4) * plane_bytes, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(outv[n * MT + m][qp], orsrc, vo + (unsigned)((chf + qp * 16) >> 4) * plane_bytes, 0, 0);
+            }
         }
     }
 }
