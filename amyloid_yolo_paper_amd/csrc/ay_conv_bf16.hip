@@ -881,8 +881,9 @@ extern "C" int ay_conv_dgrad_s2_bf16(const ay_conv_desc* d, const void* dz, cons
     // Class pairs (AY_S2_PAIR, default on): one workgroup computes BOTH column-parity classes of a row parity -- the tile's channels are
     // the two classes side by side -- so that a wave stores neighbouring pixels in consecutive instructions (whole lines reach HBM).
     static const int pair = getenv("AY_S2_PAIR") ? atoi(getenv("AY_S2_PAIR")) : 1;
-    if (pair && kin % 32 == 0) {
-        if (cin_pad % 128 == 0) return launch_dgrad_s2<256, 4, 2, 1, 8, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
+    // (the layers with 128 and more channels are compute-bound: a 256-wide pair tile leaves LDS for 16-channel stages only and
+    // measured 2-5 % slower than one class per workgroup; they keep the class form)
+    if (pair && kin % 32 == 0 && cin_pad % 128 != 0) {
         static const int pth16 = getenv("AY_S2_PAIR_TH16") ? atoi(getenv("AY_S2_PAIR_TH16")) : 1;   // 16x32-pixel items for the 32-channel layer
         if (pth16 && d->hout >= 16 && cin_pad % 64 != 0) return launch_dgrad_s2<64, 1, 8, 2, 16, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
         if (cin_pad % 64 == 0) return launch_dgrad_s2<128, 2, 4, 2, 8, true>(d, dz, w_s2_packed, ones, zeros, residual, dx, cin_pad, st);
