@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
     // phase B: as the ring kernel's 8x32 tile
     constexpr int WM = BN2 / 64, WN = 8 / WM, MT = 2, NT = (TH * TW) / (WN * 32);
     static_assert(MT * WM * 32 == BN2 && NT * WN * 32 == TH * TW, "tile split");
+#ifndef AY_RESBLOCK_RES_LDS
+#define AY_RESBLOCK_RES_LDS 1
+#endif
+    constexpr bool RES_FROM_LDS = AY_RESBLOCK_RES_LDS && MT * NT <= 4;   // 32 VGPRs of residual held from phase A to the epilogue
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     __builtin_amdgcn_s_setprio(2);  // above a co-resident merge-NMS wavefront (priority 0)
@@ -186,6 +190,13 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
         const int p = (wn * NT + n) * 32 + c;
         pb[n] = (hh * HPP + (p / TW) * IN_W + (p % TW)) * 16;
     }
+    // residual unit of output pixel p in a chunk's x slab [half][HP px][16 B]: halo pixel (ty + 1, tx + 1)
+    int rp[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        rp[n] = (hh * HP + (p / TW + 1) * IN_W + (p % TW + 1)) * 16;
+    }
     const int wa2 = (hh * BN2 + wm * MT * 32 + c) * 16;
     const int wa1 = XP * 1024 + (hh * CM + wma * 32 + c) * 16;
 
@@ -204,6 +215,7 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
         const int next_item = item + slots;
         const bool has_next = next_item < last;
 
+        ResRegs<MT, NT> rr;
         // ================= phase A: mid = leaky(bn1(W1 . x)) on the halo tile =================
         f32x16 accA[NBA];
 #pragma unroll
@@ -215,6 +227,28 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             int slot_ld = cur + (NBUF - 1);
             if (slot_ld >= NBUF) slot_ld -= NBUF;
             const uint8_t* L = lds + cur * SLOT;
+            // the shortcut operand of the epilogue is x itself: this stage's 16-channel chunk(s) of the halo tile lie in the ring slot
+            // right now, so the lanes pick their residual units (store layout: 16 bytes = channels 8hh.. of one pixel) out of LDS
+            // instead of re-reading them from L2 / HBM 20 us later, when 32 CUs x 150 KB per item have pushed them out of the 4-MB
+            // slice (the kernel fetched its input 1.91x: profiles/r02_hbm_traffic_v7.txt)
+            if constexpr (RES_FROM_LDS) {
+#pragma unroll
+                for (int kk = 0; kk < NKA; ++kk) {
+                    const int chunk = sa * NKA + kk;           // 16-channel plane of x
+                    if ((chunk >> 2) == wm) {                  // this wave's 64 output channels (wave-uniform)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const uint4 v = *reinterpret_cast<const uint4*>(L + kk * XSLAB + rp[n]);
+                            // rr.r[m][n][qp], m = (chunk >> 1) & 1, qp = chunk & 1: written through constant indices
+                            if (((chunk >> 1) & 1) == 0) {
+                                if ((chunk & 1) == 0) rr.r[0][n][0] = v; else rr.r[0][n][1] = v;
+                            } else {
+                                if ((chunk & 1) == 0) rr.r[1][n][0] = v; else rr.r[1][n][1] = v;
+                            }
+                        }
+                    }
+                }
+            }
             vec8 fa[NKA], fb[NKA][NBA];
 #pragma unroll
             for (int kk = 0; kk < NKA; ++kk) {
@@ -278,7 +312,6 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        ResRegs<MT, NT> rr;
         for (int kb = 0; kb < SB; ++kb) {
             const bool last_stage = (kb + 1 == SB);
             const bool issued = !ld_done;
@@ -317,8 +350,8 @@ __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, i
             stage_end(issued, !(last_stage && !has_next));
             if (++cur == NBUF) cur = 0;
         }
-        conv_epilogue<BN2, MT, NT, TW, false, true, true, 2, false, false, DT>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
-                                                            reinterpret_cast<const float*>(lds + OFF_SS2));
+        conv_epilogue<BN2, MT, NT, TW, false, true, !RES_FROM_LDS, 2, false, false, DT>(a, acc, rr, b, 0, wm, wn, c, hh, y0, x0,
+                                                                         reinterpret_cast<const float*>(lds + OFF_SS2));
         if (!has_next) break;
         item = next_item;
     }

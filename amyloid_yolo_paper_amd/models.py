@@ -128,7 +128,7 @@ class Darknet(nn.Module):
         self.precision = precision
         # residual blocks run through the fused kernel: C=64 (measured 1.74 ms vs 2.37 for the two launches at B=64, 512^2);
         # the C=128 kernel exists (ay_resblock_supported) but measures 1.15 vs 1.04 ms, so it is not used by default
-        self.fuse_block_channels = (64,)
+        self.fuse_block_channels = tuple(int(v) for v in os.environ.get("AY_FUSE_BLOCK_CHANNELS", "64").split(",") if v)
         self._graph = self._analyse()
         self._prep = None       # packed weights / folded BN, keyed by parameter versions
         self._act_bufs = {}      # (precision, B, S) -> per-layer device tensors
