@@ -2,7 +2,12 @@
 """Headline benchmark: tiles/s of the YOLOv3 hot path (1024x1024 RGB tiles, bf16 MFMA backbone+FPN, decode, merge-NMS)
 on MI355X.  One "step" = one pass over one batch of 64 device-resident synthetic tiles (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 runs one rank per GPU either way it is started: under `python -m torch.distributed.run --nproc-per-node N` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the environment), or from a plain `python bench.py --gpus N`, in which case this process starts the
+N ranks itself as child processes -- before it imports torch or touches HIP -- waits for them, forwards rank 0's JSON line and
+exits with their return code (`launch_ranks`).
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel
 (3x3 stride-1 MFMA convolution, BN=128 tile) timed with HIP events on the launch stream inside the timed region and
@@ -52,6 +57,9 @@ def parse():
     ap.add_argument("--cpu_tiles", type=int, default=16, help="tiles in the CPU-oracle sample (configs[0]: 16 tiles, ~12 s)")
     ap.add_argument("--serial_nms", action="store_true", help="run merge-NMS on the main stream (no overlap with the next batch)")
     ap.add_argument("--no_layer_events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--launch_probe", action="store_true",
+                    help="rank plumbing only (no GPU): every rank joins the gloo rendezvous the timed run uses, the ranks' numbers are summed "
+                         "and rank 0 prints one JSON line; tests/test_dp_cpu.py drives the self-launcher through this on CPU-only boxes")
     ap.add_argument("--traffic_json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="optional {kernel family: HBM bytes per launch} from a rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -74,8 +82,62 @@ def conv_flops(e, B, S):
     return 2.0 * B * h * h * e["cout"] * e["cin"] * e["k"] * e["k"]
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process (which has not imported torch and
+    never touches the GPU: nothing that has initialised HIP is exec'd or forked), one per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    stdout (the ONE JSON line) is forwarded as it is; the other ranks' stdout goes to stderr.  Return code: 0 when every rank
+    returned 0, else the first non-zero one; when a rank fails the others are terminated (their own PIDs), nothing is retried."""
+    import signal
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": os.environ.get("MASTER_PORT") or str(free_port())})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for o in alive:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for r in alive:
+            procs[r].send_signal(signal.SIGINT)
+        rc = 130
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -84,10 +146,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        a.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+        a.gpus = world          # the launcher's world size wins (torch.distributed.run --nproc-per-node N)
+    if a.launch_probe:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank), float(local_rank), 1.0], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"probe": "launch", "n_gpus": a.gpus, "world": world, "sum_ranks": t[0].item(), "sum_local_ranks": t[1].item(),
+                              "ranks_seen": int(t[2].item()), "master": os.environ["MASTER_ADDR"]}), flush=True)
+        dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py (rank {rank} of {world}) needs a HIP device: no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # AY_FORCE_DIST=1 walks the process-group code path with a single rank too (rehearsal of the N>1 launch on a 1-GPU box)
@@ -278,7 +351,8 @@ def main():
             if USE_DIST:
                 group = dist.new_group(backend="nccl", device_id=dev)
             tr = measure_train(a, rank, world, dev, a.train_batch, a.leg_train_size, a.leg_train_steps, 2, group=group)
-            result["train"] = {k: tr[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline") if k in tr}
+            result["train"] = {k: tr[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
+                                                    "all_reduce_bytes", "all_reduce_buckets", "roofline") if k in tr}
         except Exception as exc:  # the headline number stands on its own
             result["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
@@ -355,6 +429,8 @@ def measure_train(a, rank, world, dev, B, S, steps, warmup, group=None):
         elapsed = float(t.item())
     lv = [float(l.item()) for l in losses]
     assert all(v == v and abs(v) != float("inf") for v in lv), "non-finite training loss"
+    ar_bytes = red.flat.numel() * 4 if red._active() else 0     # fp32 gradient bytes each rank contributes to the exchange, per step
+    n_buckets = len(red.buckets)
     flops_per_img = 3.0 * sum(conv_flops(e, 1, 1024) for e in model._graph if e["type"] == "convolutional") * (S / 1024.0) ** 2
     ctx_bytes = sum(c.bytes() for c in getattr(model, "_train_ctx", {}).values())
     result = {
@@ -366,6 +442,7 @@ def measure_train(a, rank, world, dev, B, S, steps, warmup, group=None):
                    "global_batch": world * B, "tile": S, "parallelism": f"dp{world}", "first_loss": round(lv[0], 3), "last_loss": round(lv[-1], 3),
                    "model_tflops": round(world * B * steps * flops_per_img / elapsed / 1e12, 1),
                    "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "saved_activations_gb": round(ctx_bytes / 1e9, 1)},
+        "all_reduce_bytes": ar_bytes, "all_reduce_buckets": n_buckets if ar_bytes else 0,
     }
     prof = getattr(model, "_train_prof", None)
     if prof and prof["wgrad"]:

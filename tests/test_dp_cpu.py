@@ -195,3 +195,51 @@ def test_reducer_single_process_is_noop():
     m(torch.randn(2, 3, 4, 4)).sum().backward()
     before = red.flat.clone()
     assert red.all_reduce() == 0 and torch.equal(before, red.flat)
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus N` from a plain start ---------------------------------------
+
+def _run_bench(*args, timeout=240):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launch_starts_one_rank_per_gpu_and_forwards_rank0():
+    """world 2 over gloo through the launcher: both ranks rendezvous on 127.0.0.1, exactly one JSON line comes back on stdout"""
+    import json
+    r = _run_bench("--gpus", "2", "--launch_probe")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert (j["world"], j["n_gpus"], j["ranks_seen"], j["sum_ranks"], j["sum_local_ranks"], j["master"]) == (2, 2, 2, 1.0, 1.0, "127.0.0.1")
+
+
+def test_bench_self_launch_fails_cleanly_in_the_children_without_a_gpu():
+    """on a CPU-only box the launcher itself never touches torch.cuda: the CHILDREN report the missing device, the launcher stops the
+    other rank and returns non-zero; no JSON line, no retry"""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a HIP device")
+    r = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert r.returncode != 0
+    assert "needs a HIP device" in r.stderr and "rank 0 of 2" in r.stderr + r.stdout
+    assert "stopping the other ranks" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_under_torch_distributed_run_keeps_the_launchers_world():
+    """the driver's form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 (WORLD_SIZE set: no self-launch)"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--launch_probe"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["world"] == 2 and j["ranks_seen"] == 2
