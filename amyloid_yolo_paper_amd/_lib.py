@@ -7,6 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libamyloid_yolo_hip.so")
+ABI_VERSION = 2   # include/amyloid_yolo.h: AY_ABI_VERSION this binding's signatures (_SIGS) were written against
 
 
 class ConvDesc(C.Structure):
@@ -142,6 +143,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m amyloid_yolo_paper_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
         l = C.CDLL(LIB_PATH)
+        l.ay_version.restype = C.c_int
+        have = l.ay_version()
+        if have != ABI_VERSION:   # a stale .so would take e.g. ay_plan_create's out pointer for a dtype: refuse it before any call
+            raise AyError(f"{LIB_PATH} exports ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+                          "(python -m amyloid_yolo_paper_amd.build --force)")
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError here = header/library mismatch
             fn.restype = res

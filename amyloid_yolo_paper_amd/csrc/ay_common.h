@@ -76,6 +76,7 @@ struct Bf16 {
     static __device__ __forceinline__ f32x2 unpack2(uint32_t u) { return bf2f2(u); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return f2bf(f); }
     static __device__ __forceinline__ float to_f32(uint16_t u) { return bf2f(u); }
+    static __device__ __forceinline__ void enter() {}   // (F16::enter sets a conversion mode bit; bfloat16 shares fp32's range)
 };
 struct F16 {
     typedef f16x8 vec8;
@@ -85,6 +86,12 @@ struct F16 {
     static __device__ __forceinline__ uint32_t pack2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t)); }
     static __device__ __forceinline__ f32x2 unpack2(uint32_t u) { return __builtin_convertvector(__builtin_bit_cast(f16x2_t, u), f32x2); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    // Called first thing by every kernel that stores halves: MODE.FP16_OVFL = 1 (hwreg 1 = MODE, bit 23): a conversion that
+    // overflows the half range SATURATES at +-65504 instead of producing +-inf; true infinities and NaNs pass through.  A
+    // post-BatchNorm or post-shortcut value beyond 65504 (the residual stream of Darknet-53 adds without bound across blocks; the
+    // synthetic weights stay below 2 300) would otherwise become inf and turn into NaN one layer later without a diagnostic.
+    // Free: a mode bit, no instruction per value.
+    static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
     static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 };
 template <typename DT>

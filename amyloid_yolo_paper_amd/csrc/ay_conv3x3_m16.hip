@@ -48,6 +48,7 @@ __device__ unsigned long long g_phase_ticks_m16[8];
 
 template <bool HAS_RES, typename DT = Bf16>
 __global__ void __launch_bounds__(512, 2) conv3x3_m16_ring_kernel(ConvArgs a, int n_items) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int BN = 128, TH = 16, TW = 32;
     constexpr int IN_W = TW + 2, IN_PIX = (TH + 2) * IN_W;  // 18 x 34 halo tile

@@ -27,6 +27,7 @@ namespace ay {
 
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES, typename DT = Bf16>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
@@ -205,6 +206,7 @@ __device__ unsigned g_deal[DEAL_STREAMS * DEAL_SETS][16];
 template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, int NBUF, bool HAS_RES, bool CAT = false, bool CANVAS = false,
           typename DT = Bf16, bool PAIR = false>
 __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int n_items) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     // PAIR (2x2-window kernels only): the tile's BN "channels" are the two column-parity classes of BN / 2 real channels, side by side
     // (ay_conv_common.h: pair_block); the channel-group index then carries the ROW parity in its low bit

@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...) {
 template <typename DT>
 __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cout_pad,
                                     int cin, int ks) {
+    DT::enter();
     const int kk2 = ks * ks;
     const size_t total = (size_t)(cin / 16) * kk2 * 2 * cout_pad * 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -59,6 +60,7 @@ template <typename DT>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         uint8_t* __restrict__ out, int H, int W, int leaky) {
+    DT::enter();
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -125,6 +127,7 @@ __global__ void concat_upsample_kernel(const uint8_t* __restrict__ s1, int p1, i
 
 template <typename T, typename DT = Bf16>
 __global__ void blocked_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W) {
+    DT::enter();
     const size_t total = (size_t)B * C * H * W;
     const int CP = (C + 15) / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -145,6 +148,7 @@ __global__ void blocked_to_nchw_kernel(const T* __restrict__ src, float* __restr
 template <typename DT>
 __global__ void nchw_to_blocked_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int B, int C, int H,
                                             int W) {
+    DT::enter();
     const int CP = (C + 15) / 16;
     const size_t total = (size_t)B * CP * H * W * 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -174,7 +178,7 @@ static inline unsigned grid_for(size_t n, int block) {
 
 using namespace ay;
 
-extern "C" int ay_version(void) { return 1; }
+extern "C" int ay_version(void) { return AY_ABI_VERSION; }
 extern "C" const char* ay_last_error(void) { return ay::g_err; }
 
 extern "C" size_t ay_packed_weight_bytes(int cout_pad, int cin, int ksize) {

@@ -4,10 +4,15 @@
 //                       (:253), appends a 64-bit sort key per candidate: (~score_bits << 32) | row, so an
 //                       ascending sort = score descending, ties -> lower original row first.
 //   nms_merge_kernel    one workgroup per image: bitonic sort of the keys (LDS when they fit), gather of the
-//                       candidates in sorted order, then the greedy class-aware scan (:260-269) by one
-//                       64-lane wavefront: the "alive" set is a bitmask of 64-bit words, each lane tests one
-//                       candidate of a word against the current head, __ballot() gives the suppression mask
-//                       of the word, the members' conf-weighted corner sums are wave-reduced for the merge.
+//                       candidates in sorted order, then the greedy class-aware scan (:260-269): the "alive" set
+//                       is a bitmask of 64-bit words, each lane tests one candidate of a word against the current
+//                       head, __ballot() gives the suppression mask of the word, the members' conf-weighted corner
+//                       sums are wave-reduced for the merge.  Up to 1 024 candidates (the LDS path) the scan runs on
+//                       FOUR wavefronts: a cluster only ever holds rows of one class (:262-264), so the candidates
+//                       split into four class partitions (class & 3) whose greedy scans are independent; a wave keeps
+//                       its partition's alive words in registers and walks all of them per head in one unrolled pass.
+//                       The heads of all partitions are emitted in global score order by a prefix count over the head
+//                       bitmap.  Larger candidate sets take the one-wavefront scan over the workspace.
 //
 // IoU uses the reference's +1-pixel rule and operation order (fp32, no contraction) so `> nms_thres`
 // decisions are bit-identical; only the merged corners (a sum whose order the reference does not fix)
@@ -87,6 +92,13 @@ __global__ void nms_filter_kernel(float* __restrict__ pred, int N, int C, float 
     }
 }
 
+// candidate counters start at zero: a kernel rather than a memset, so that a captured detection step consists of this library's
+// kernel nodes only
+__global__ void nms_zero_counts_kernel(int* cand_count, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch) cand_count[i] = 0;
+}
+
 template <typename P>
 __device__ void bitonic_sort(P d, int n, int tid, int nthreads) {
     for (int k = 2; k <= n; k <<= 1) {
@@ -108,6 +120,8 @@ __device__ void bitonic_sort(P d, int n, int tid, int nthreads) {
 }
 
 constexpr int NMS_FAST = 1024;      // candidates per image whose arrays the fast path keeps in LDS (32 KiB)
+constexpr int NMS_WORDS = NMS_FAST / 64;
+constexpr int NMS_PARTS = 4;        // class partitions (class & 3) = wavefronts of the workgroup
 constexpr int NMS_LDS_KEYS = 1024;  // 8 KiB of keys sorted in LDS (larger candidate sets sort in the workspace): with the 8-KiB alive mask the
                                     // workgroup stays at 16 KiB of LDS, so it can share a CU with a persistent convolution workgroup of the next
                                     // batch (117-144 KiB) instead of keeping 64 CUs away from it
@@ -119,7 +133,8 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
                                                         int* __restrict__ count, unsigned long long* alive_ws) {
     __shared__ unsigned long long skeys[NMS_LDS_KEYS];
     __shared__ float fc[8][NMS_FAST];  // fast path: x1, y1, x2, y2, conf, class, class conf, original row (as int) in sorted order
-    __shared__ unsigned long long alive_s[NMS_FAST / 64];  // fast path only; the workspace path keeps its alive words in the workspace
+    __shared__ unsigned long long head_s[NMS_PARTS][NMS_WORDS];  // fast path: head bitmap per class partition, then ([0]) their union
+    __shared__ int wpre[NMS_WORDS];                              // fast path: heads in the words below
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int K = 5 + C;
@@ -171,43 +186,50 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
             fc[6][i] = mc;
             reinterpret_cast<int*>(fc[7])[i] = r;
         }
-        const int nwords = (n + 63) >> 6;
-        volatile unsigned long long* alive = alive_s;
-        for (int i = tid; i < nwords; i += 256) {
-            const int rem = n - i * 64;
-            alive[i] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-        }
         __syncthreads();
-        if (tid >= 64) return;
-        const int lane = tid;
-        int kept = 0, cw = 0;
+        const int nwords = (n + 63) >> 6;   // <= NMS_WORDS
+        const int lane = tid & 63;
+        const int part = tid >> 6;          // this wavefront scans the candidates whose class & 3 == part
+        // ---- this partition's alive words, in registers (wave-uniform values: every loop over them is fully unrolled) ----------
+        unsigned long long al[NMS_WORDS], hm[NMS_WORDS];
+#pragma unroll
+        for (int w = 0; w < NMS_WORDS; ++w) {
+            const int j = w * 64 + lane;
+            const bool mine = w < nwords && j < n && (((int)fc[5][min(j, NMS_FAST - 1)]) & 3) == part;
+            al[w] = __ballot(mine);
+            hm[w] = 0ull;
+        }
         while (true) {
-            unsigned long long aw = 0;
-            while (cw < nwords && (aw = alive[cw]) == 0ull) ++cw;  // wave-uniform
-            if (cw >= nwords) break;
-            const int head = cw * 64 + __builtin_ctzll(aw);
+            int head = -1;
+#pragma unroll
+            for (int w = 0; w < NMS_WORDS; ++w)
+                if (head < 0 && al[w] != 0ull) head = w * 64 + __builtin_ctzll(al[w]);
+            if (head < 0) break;   // wave-uniform
             const float hx1 = fc[0][head], hy1 = fc[1][head], hx2 = fc[2][head], hy2 = fc[3][head], hcls = fc[5][head];
             float sw = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int w = cw; w < nwords; ++w) {
-                const unsigned long long a = alive[w];
-                if (a == 0ull) continue;
-                const int j = w * 64 + lane;
-                bool member = (j == head);  // the head always leaves the set (also when its IoU is NaN)
-                if ((a >> lane) & 1ull) {
-                    const float x1 = fc[0][j], y1 = fc[1][j], x2 = fc[2][j], y2 = fc[3][j];
-                    const float iou = iou_p1(hx1, hy1, hx2, hy2, x1, y1, x2, y2);
-                    member = member || ((iou > nms_thres) && (fc[5][j] == hcls));
-                    if (member) {
-                        const float wgt = fc[4][j];
-                        sw += wgt;
-                        s0 += wgt * x1;
-                        s1 += wgt * y1;
-                        s2 += wgt * x2;
-                        s3 += wgt * y2;
+            // (the members of a cluster meet the lanes in the order of the one-wavefront scan -- ascending word, lane = position in the
+            // word -- so the partial sums, and with them the merged corners, are the same bits)
+#pragma unroll
+            for (int w = 0; w < NMS_WORDS; ++w) {
+                const unsigned long long a = al[w];
+                if (a != 0ull && w * 64 + 63 >= head) {   // wave-uniform
+                    const int j = w * 64 + lane;
+                    bool member = (j == head);  // the head always leaves the set (also when its IoU is NaN)
+                    if ((a >> lane) & 1ull) {
+                        const float x1 = fc[0][j], y1 = fc[1][j], x2 = fc[2][j], y2 = fc[3][j];
+                        const float iou = iou_p1(hx1, hy1, hx2, hy2, x1, y1, x2, y2);
+                        member = member || ((iou > nms_thres) && (fc[5][j] == hcls));
+                        if (member) {
+                            const float wgt = fc[4][j];
+                            sw += wgt;
+                            s0 += wgt * x1;
+                            s1 += wgt * y1;
+                            s2 += wgt * x2;
+                            s3 += wgt * y2;
+                        }
                     }
+                    al[w] = a & ~__ballot(member);
                 }
-                const unsigned long long m = __ballot(member);
-                if (lane == 0) alive[w] = a & ~m;
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -217,21 +239,55 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
                 s2 += __shfl_xor(s2, off);
                 s3 += __shfl_xor(s3, off);
             }
-            if (lane == 0 && kept < max_det) {
-                float* o = out_rows + ((size_t)b * max_det + kept) * 7;
-                o[0] = s0 / sw;
-                o[1] = s1 / sw;
-                o[2] = s2 / sw;
-                o[3] = s3 / sw;
-                o[4] = fc[4][head];
-                o[5] = fc[6][head];
-                o[6] = hcls;
-                keep_idx[(size_t)b * max_det + kept] = reinterpret_cast<const int*>(fc[7])[head];
+            // the head's own entry is never read again (it has left every alive set, and other partitions never look at it): it
+            // carries the merged corners to the emission pass
+            if (lane == 0) {
+                fc[0][head] = s0 / sw;
+                fc[1][head] = s1 / sw;
+                fc[2][head] = s2 / sw;
+                fc[3][head] = s3 / sw;
             }
-            ++kept;
+#pragma unroll
+            for (int w = 0; w < NMS_WORDS; ++w)
+                if ((head >> 6) == w) hm[w] |= 1ull << (head & 63);
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) count[b] = kept;
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 0; w < NMS_WORDS; ++w) head_s[part][w] = hm[w];
+        }
+        __syncthreads();
+        // ---- emission in global score order (:273 appends the heads as the loop meets them): rank = heads at lower sorted positions
+        if (tid < NMS_WORDS) {
+            unsigned long long m = 0ull;
+            for (int k = 0; k < NMS_PARTS; ++k) m |= head_s[k][tid];
+            head_s[0][tid] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < NMS_WORDS; ++w) {
+                wpre[w] = acc;
+                acc += __builtin_popcountll(head_s[0][w]);
+            }
+            count[b] = acc;  // > max_det means the caller's buffers were too small (rows were dropped)
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const unsigned long long m = head_s[0][i >> 6];
+            if (!((m >> (i & 63)) & 1ull)) continue;
+            const int rank = wpre[i >> 6] + __builtin_popcountll(m & ((1ull << (i & 63)) - 1ull));
+            if (rank >= max_det) continue;
+            float* o = out_rows + ((size_t)b * max_det + rank) * 7;
+            o[0] = fc[0][i];
+            o[1] = fc[1][i];
+            o[2] = fc[2][i];
+            o[3] = fc[3][i];
+            o[4] = fc[4][i];
+            o[5] = fc[6][i];
+            o[6] = fc[5][i];
+            keep_idx[(size_t)b * max_det + rank] = reinterpret_cast<const int*>(fc[7])[i];
+        }
         return;
     }
     // ---- gather candidates in sorted order (:255-258) -------------------------------------------
@@ -355,10 +411,8 @@ extern "C" int ay_nms_filter(float* pred, int batch, int n_rows, int num_classes
     if (int rc = nms_args_ok(batch, n_rows, num_classes, workspace_bytes, "ay_nms_filter")) return rc;
     hipStream_t st = S(stream);
     const int cap = next_pow2(n_rows);
-    if (hipMemsetAsync(cand_count, 0, sizeof(int) * batch, st) != hipSuccess) {
-        set_error("ay_nms_filter: memset failed");
-        return AY_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(nms_zero_counts_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, cand_count, batch);
+    AY_CHECK_LAUNCH("nms_zero_counts_kernel");
     int gx = (n_rows + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(nms_filter_kernel, dim3(gx, batch), dim3(256), 0, st, pred, n_rows, num_classes, conf_thres,

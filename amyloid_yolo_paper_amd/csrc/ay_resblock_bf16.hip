@@ -35,6 +35,7 @@ struct ResBlockArgs {
 
 template <int CM, int TH, int NKA, int NBUF, typename DT = Bf16>   // mid channels; tile rows; 16-channel chunks of x per phase-A stage; ring depth; storage type
 __global__ void __launch_bounds__(512, 2) resblock_bf16_kernel(ResBlockArgs s, int n_items) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int C = 2 * CM;
     constexpr int TW = 32, IN_W = TW + 2, IN_H = TH + 2;

@@ -40,6 +40,7 @@ struct StemFusedArgs {
 // 16 waves: every phase is a chain of dependent LDS round trips per wave, so more (shorter) chains per CU, not wider ones
 template <typename DT>
 __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, int n_items) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int TH = 8, TW = 32, BN = 64;
     constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 17 x 65 stem pixels feed the tile
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__(1024) stem_s2_fused_kernel(StemFusedArgs s, in
 //     registers, LeakyReLU is max(t, slope t), two values per convert
 template <typename DT>
 __global__ void __launch_bounds__(1024) stem_s2_fused_v2_kernel(StemFusedArgs s, int n_items) {
+    DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int TH = 4, TW = 32, BN = 64;
     constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;      // 9 x 65 stem pixels feed the tile

@@ -18,13 +18,14 @@ from .utils import load_classes, non_max_suppression, rescale_boxes
 
 def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_path="weights/yolov3.weights",
            class_path=None, conf_thres=0.8, nms_thres=0.4, batch_size=1, n_cpu=0, img_size=416, precision="bf16",
-           rescale=True, verbose=True, device_ingest=True, merge_boxes=False, write_CAA_detections_to_pickle=False,
+           rescale=True, verbose=True, device_ingest=True, merge_boxes=False, merge_on_device=False, write_CAA_detections_to_pickle=False,
            filter_CAA_detections_by_model=False):
     """``precision``: "bf16" | "fp16" (the two 16-bit MFMA storage types) | "fp32" (reference-precision parity path).
     ``device_ingest``: upload the decoded uint8 tiles and do /255 + pad-to-square + nearest resize on the GPU
     (``ay_ingest_tiles_u8``, bit-identical to the host transforms); batches of mixed image sizes are ingested one size at a time.
     ``merge_boxes``: the reference's ``--merge_boxes True`` (``detect.py:131-133``): union-merge overlapping same-class boxes
-    after the rescale (``postprocess.merge_detections``).
+    after the rescale (``postprocess.merge_detections``: the reference's container semantics on the host; ``merge_on_device=True``
+    sends all images through one ``ay_merge_detections`` launch instead -- same rows as sets, explicit row order).
     ``write_CAA_detections_to_pickle`` / ``filter_CAA_detections_by_model`` (reference ``detect.py:43-44,134-141``) belong to the
     paper's second-stage CAA classifier (``core.filterDetectionsByCAAModel`` / ``writeCAADetectionsToPickle``: cv2, skimage and
     a Git-LFS model pickle): accepted so that existing command lines parse, refused with a clear error when switched on."""
@@ -74,8 +75,11 @@ def detect(image_folder="data/samples", model_def="config/yolov3.cfg", weights_p
                 w, h = Image.open(path).size
                 rescale_boxes(det, img_size, (h, w))
     if merge_boxes:
-        from .postprocess import merge_detections
-        results = [None if det is None else merge_detections(det) for det in results]
+        from .postprocess import merge_detections, merge_detections_batch_device
+        if merge_on_device:
+            results = merge_detections_batch_device(results)
+        else:
+            results = [None if det is None else merge_detections(det) for det in results]
     return paths, results, classes
 
 

@@ -63,6 +63,30 @@ def merge_detections(detections):
     return torch.as_tensor([list(e) for e in entries])
 
 
+def merge_detections_batch_device(dets):
+    """``detect(merge_boxes=True, merge_on_device=True)``: a list of per-image ``[n,7]`` tensors (or None) through ONE
+    ``ay_merge_detections`` launch (one wavefront per image) -> the same list form.  Row order is the kernel's explicit one (input
+    order, merged rows appended), where ``merge_detections`` keeps the reference's set-iteration order: equal as sets of rows unless
+    a chain of merges makes the reference itself order-dependent."""
+    import torch
+    from . import _lib
+    n = [0 if d is None else int(d.shape[0]) for d in dets]
+    if not dets or max(n) == 0:
+        return list(dets)
+    cap = _lib.lib().ay_merge_detections_max_rows()
+    if max(n) > cap:
+        raise _lib.AyError(f"merge_detections_batch_device: an image holds {max(n)} rows (at most {cap})")
+    M = max(n)   # a merge replaces two rows by one: an image never holds more rows than it came with
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rows = torch.zeros(len(dets), M, 7, dtype=torch.float32)
+    for b, d in enumerate(dets):
+        if n[b]:
+            rows[b, :n[b]] = d.detach().to(dtype=torch.float32, device="cpu")
+    out, cnt = merge_detections_device(rows.to(dev), torch.tensor(n, dtype=torch.int32, device=dev))
+    out, cnt = out.cpu(), cnt.cpu().tolist()
+    return [None if n[b] == 0 else out[b, :cnt[b]].clone() for b in range(len(dets))]
+
+
 def merge_detections_device(rows, count):
     """``rows`` [B, max_rows, 7] float32 CUDA tensor of (x1, y1, x2, y2, conf, cls_conf, cls_pred), ``count`` [B] int32 valid rows per
     image (what ``utils.nms_device`` returns, after rescaling) -> (merged rows [B, max_rows, 7], merged count [B]) on the device,
@@ -74,7 +98,7 @@ def merge_detections_device(rows, count):
     if M > L.ay_merge_detections_max_rows():
         raise _lib.AyError(f"merge_detections_device: {M} rows per image (at most {L.ay_merge_detections_max_rows()})")
     count = count.to(device=rows.device, dtype=torch.int32).contiguous()
-    out = torch.empty_like(rows)
+    out = torch.zeros_like(rows)          # the kernel writes the first out_count[b] rows of an image: the tail reads as zeros
     out_count = torch.empty_like(count)
     _lib.check(L.ay_merge_detections(_lib.ptr(rows), _lib.ptr(count), B, M, _lib.ptr(out), _lib.ptr(out_count), _lib.stream_ptr()),
                "ay_merge_detections")

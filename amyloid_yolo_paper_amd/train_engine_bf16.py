@@ -257,6 +257,7 @@ def train_forward_bf16(model, x, targets):
         off += 4 * graph[j]["cout"]
     bn_ws_flat = ctx.get("bn_ws_flat", (max(off, 1),), torch.float64)
     bn_ws_flat.zero_()
+    ctx.bn_ws_clean = True    # the backward halves are zero: ONE backward pass may accumulate into them (train_backward_bf16)
 
     def bn_ws(j, backward):
         o = bn_off[j] + (2 * graph[j]["cout"] if backward else 0)
@@ -417,6 +418,12 @@ def train_backward_bf16(model, stt, grad_scale=None):
     packed = ctx.packed
     dev = ctx.dev
     dval = {}
+    # ay_bn_train_bwd_bf16_acc_zeroed_ws ADDS its fp64 sums onto the workspace and trusts it to be zero.  The forward cleared it; a
+    # second backward over the same state (or one without a fresh forward of this (B, S) context) would add onto dirty sums and give
+    # silently wrong dgamma / dbeta / dz: clear it here then (the forward halves are not read again: mean / invstd are saved per layer)
+    if not getattr(ctx, "bn_ws_clean", False):
+        ctx.buf["bn_ws_flat"].zero_()
+    ctx.bn_ws_clean = False
     for p in model.parameters():
         if p.grad is None:
             p.grad = torch.zeros_like(p)

@@ -41,6 +41,11 @@ typedef void* ay_stream_t; /* hipStream_t */
 #define AY_DT_BF16 0
 #define AY_DT_F16 1
 
+/* ABI version of this header: bumped whenever an exported signature changes (2: ay_plan_create gained `act_dtype` in the middle of
+ * its argument list).  A binding compares ay_version() with the version it was written against before the first call, so that a
+ * stale libamyloid_yolo_hip.so (or an out-of-tree caller of the old 7-argument form) fails at load time instead of passing a pointer
+ * as a dtype (amyloid_yolo_paper_amd/_lib.py: ABI_VERSION). */
+#define AY_ABI_VERSION 2
 int ay_version(void);
 const char* ay_last_error(void);
 

@@ -191,8 +191,12 @@ class OracleDarknet:
             y = F.leaky_relu(y, 0.1)
         return y
 
-    def forward(self, x, targets=None, mode="fp32", train_bn=False, collect=False, stem_bf16=True, forced=None):
+    def forward(self, x, targets=None, mode="fp32", train_bn=False, collect=False, stem_bf16=True, forced=None, layer_modes=None):
         """x [B,3,S,S] float32 tensor.  Returns outputs [B,N,5+C] (and loss if targets).
+
+        ``layer_modes`` (inference experiments, oracle/parity_sweep.py): callable layer index -> "bf16" | "fp16" | "fp32", the storage
+        type of that layer's filters and of its stored output (a shortcut's sum is stored in the type of the shortcut layer's index);
+        overrides ``mode`` per layer.
 
         ``forced`` (``mode="bf16_train"`` only) = {"z": {layer: NCHW fp32}, "y": {layer: NCHW fp32}}: stored raw convolution
         outputs and stored layer outputs of the implementation under test.  Each layer is then evaluated on the forced inputs,
@@ -217,8 +221,12 @@ class OracleDarknet:
         yolo_out, loss = [], 0
         self.metrics = []
         rnd = _bf16 if mode == "bf16" else _fp16 if mode == "fp16" else _ste if mode == "bf16_train" else (lambda t: t)
+        mode0 = mode
         for i, d in enumerate(self.defs):
             t = d["type"]
+            if layer_modes is not None:
+                mode = layer_modes(i)
+                rnd = _bf16 if mode == "bf16" else _fp16 if mode == "fp16" else (lambda t: t)
             if t == "convolutional":
                 xf = self._conv_block(i, d, x, mode, train_bn, stem_bf16, fz.get(i))
                 is_head = not int(d["batch_normalize"])

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(dll, name), f"{name} declared in include/amyloid_yolo.h but not exported"
     assert sorted(_lib.exported_symbols()) == declared  # the ctypes table binds all of them, and nothing else
-    assert _lib.lib().ay_version() >= 1
+    assert _lib.lib().ay_version() == _lib.ABI_VERSION == 2   # include/amyloid_yolo.h: AY_ABI_VERSION
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 # Round 3: the same contract on IEEE-half storage (precision="fp16", an 11-bit significand against bf16's 8: every rounding step 8x
 # smaller, same bytes, same MFMA rate) attains, by the CPU oracle in mode="fp16" on this tile (fp32 / float64 sums): 0.9957 / 1.0 of
 # the 230 kept indices, 0.017 / 0.021 extra heads, matched confidences within 0.0027, matched boxes within 0.168 of the box size
-# (one cluster gains a member).  The half path is the bench default and is held to that level.
+# (one cluster gains a member).  The half path (bench.py --dtype fp16, `other_dtype` / `parity_fp16` of every default line) is held to that level.
 BARS = {   # keep_match >=, extra_heads <=, max_box_rel <=, max_dconf <=, decoded-sample dconf q99 <=, box rel q99.9 <=
     "bf16": (0.78, 0.16, 0.40, 0.03, 2e-2, 5e-2),
     "fp16": (0.98, 0.035, 0.20, 0.004, 2.5e-3, 6.25e-3),
@@ -75,21 +75,19 @@ def test_configs1_bf16_b64_1024(golden_dir, tmp_cfg_dir, precision):
 
 def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):
     """One detection step (native plan forward + decode + merge-NMS) captured as a HIP graph (torch.cuda.CUDAGraph on a side
-    stream), replayed after interleaved eager steps on other inputs: same bytes as the eager step on the same input.
+    stream), replayed UNFENCED -- a bare `g.replay()` followed by a device synchronisation, the form that failed in round 2 -- after
+    interleaved eager steps on other inputs that use the same arena, output slot and NMS buffers: same bytes as the eager step on the
+    same input.
 
-    History.  Round 1 saw a GPU memory fault in this scenario; round 2 hardened what a launch carries outside a graph (per-stream
-    work-counter sets with clamped item ids, persistent NMS result buffers, no allocation inside a captured region, NMS keys
-    bounded), then measured 9 of 10 UNFENCED replays inconsistent or faulting and 12 of 12 fenced ones correct, and attributed
-    that to the runtime ("launches and stream / device synchronisation after hipGraphLaunch do not wait for the graph's last
-    node").  Round 3 tested the attribution in isolation and withdrew it: scripts/micro/graph_sync.hip (a captured kernel that
-    spins 40 ms and sets a flag last: hipStreamSynchronize, hipDeviceSynchronize, an event and a following kernel ALL see the flag,
-    60 of 60 observations, null / blocking / non-blocking streams, capture on a side stream) and graph_coherence.hip (a kernel
-    launched behind a replay reads every word the graph wrote, 0 stale reads in 64 runs); and this test with
-    AY_TEST_GRAPH_WAIT=devsync -- the variant that failed 8 of 8 times in round 2 -- passed 4 of 4 times on the current tree
-    (static and dynamic item dealing).  The round-2 failures are not reproduced; nothing in the kernels or in the runtime is
-    known to be wrong.  The replay here goes through `utils.graph_replay` = replay + `ay_stream_fence` (a library-owned event
-    recorded on the stream and waited for by the same stream: a stream-ordered no-op), the supported way to replay a step.
-    AY_TEST_GRAPH_WAIT selects the bare waits (devsync / streamsync / tolist / event / waitevent) for diagnosis."""
+    Record.  Rounds 1-2 saw GPU memory faults and inconsistent replays here.  The retained failing logs
+    (gpurun_out/r2/graph{1,2,4,6}.log) all predate the two product fixes of that afternoon: a candidate counter that does not start
+    at zero no longer turns into key writes past an image's array (`nms_filter_kernel`), and an item id fetched from a work counter
+    is clamped to the launch's own range.  Three isolating experiments without torch or product kernels then cleared the runtime:
+    every wait covers a replayed graph (scripts/micro/graph_sync.hip), a kernel behind a replay sees its writes (graph_coherence.hip),
+    and a replay sees eager writes to its inputs while its nodes see each other's writes with every L2 warmed on older contents
+    (graph_input_coherence.hip, round 4: 0 of 32 768 workgroup-results wrong).  Since round 4 a captured step holds kernel nodes of this
+    library only (the candidate counters are zeroed by a kernel, not a memset node).  AY_TEST_GRAPH_WAIT=fence replays through
+    `utils.graph_replay` (replay + `ay_stream_fence`); the other values select the bare waits of the round-2 comparison."""
     from amyloid_yolo_paper_amd.utils import nms_device
     dev = torch.device("cuda", 0)
     m, _ = build_models(3, tmp_cfg_dir, dev, "bf16")
@@ -116,7 +114,7 @@ def test_hip_graph_of_a_detection_step_replays_after_eager_steps(tmp_cfg_dir):
         eager = snapshot(step(xs[2 - k if k != 1 else 1]))   # eager steps in between (they rotate the same counter sets and buffers)
         del eager
         static_x.copy_(xs[k])
-        wait = os.environ.get("AY_TEST_GRAPH_WAIT", "fence")
+        wait = os.environ.get("AY_TEST_GRAPH_WAIT", "devsync")
         if wait == "fence":
             ay.graph_replay(g)                  # replay + event fence, no host wait
         else:

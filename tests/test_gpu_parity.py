@@ -232,6 +232,48 @@ def test_conv_bf16_kernel(dev, case, dtype):
         assert float(full[:, cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(128, 256, 3, 1, 40), (256, 128, 1, 1, 13), (128, 256, 3, 2, 26)], ids=lambda c: "x".join(str(v) for v in c))
+def test_half_storage_saturates_instead_of_overflowing(dev, case):
+    """precision="fp16": a stored value beyond the half range comes out as +-65504 (MODE.FP16_OVFL, set by every kernel that stores
+    halves), not as +-inf that the next layer turns into NaN; true infinities and NaNs in the INPUT of a conversion pass through."""
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    # the layout converter (fp32 NCHW -> blocked half)
+    v = torch.tensor([1.0, 65504.0, 65520.0, 1e6, -3e38, float("inf"), float("-inf"), float("nan")] * 2).view(1, 16, 1, 1).to(dev)
+    vb = torch.empty(1, 1, 1, 1, 16, device=dev, dtype=torch.float16)
+    check(L.ay_nchw_f32_to_blocked_f16(ptr(v), ptr(vb), 1, 16, 1, 1, st))
+    got = vb.view(-1)[:8].float().cpu()
+    assert got[:5].tolist() == [1.0, 65504.0, 65504.0, 65504.0, -65504.0], got
+    assert got[5] == float("inf") and got[6] == float("-inf") and bool(torch.isnan(got[7]))
+    # a convolution block whose fp32 results lie far outside the half range (scale 1e6): m16 / 1x1 ring / stride-2 ring epilogues
+    cin, cout, k, stride, H = case
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, H, generator=g).to(torch.float16).float()
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    pad = (k - 1) // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    ref = F.leaky_relu(F.conv2d(x, w.to(torch.float16).float(), None, stride, pad) * 1e6, 0.1).clamp(-65504.0, 65504.0)
+    xb = torch.empty(B, cin // 16, H, H, 16, device=dev, dtype=torch.float16)
+    xd, wd = x.to(dev), w.to(dev)
+    check(L.ay_nchw_f32_to_blocked_f16(ptr(xd), ptr(xb), B, cin, H, H, st))
+    packed = torch.empty(L.ay_packed_weight_bytes(cout, cin, k), device=dev, dtype=torch.uint8)
+    check(L.ay_pack_conv_weights_f16(ptr(wd), ptr(packed), cout, cout, cin, k, st))
+    sc = torch.full((cout,), 1e6, device=dev)
+    sh = torch.zeros(cout, device=dev)
+    ob = torch.empty(B, cout // 16, Ho, Ho, 16, device=dev, dtype=torch.float16)
+    d = ConvDesc(B, cin, cout, H, H, Ho, Ho, k, stride, 1, 0, cout)
+    check(L.ay_conv_fwd_f16(C.byref(d), ptr(xb), ptr(packed), ptr(sc), ptr(sh), None, ptr(ob), st), "conv")
+    got = torch.empty(B, cout, Ho, Ho, device=dev)
+    check(L.ay_blocked_f16_to_nchw_f32(ptr(ob), ptr(got), B, cout, Ho, Ho, st))
+    got = got.cpu()
+    assert torch.isfinite(got).all() and float(got.max()) == 65504.0 and float(got.min()) < -6e4
+    sat = ref.abs() >= 65504.0
+    assert bool(sat.any()) and torch.equal(got[sat], ref[sat])            # every overflowing value is the signed maximum
+    inside = ref.abs() < 6e4
+    assert bool(((got - ref).abs()[inside] <= ref.abs()[inside] * 2.0 ** -9 + 1.0).all())
+
+
 F32_CASES = [
     # cin1, cin2, up1, cout, k, stride, H, leaky, has_res, B      (cin = cin1 + cin2)
     (3, 0, 0, 32, 3, 1, 70, True, False, 2),       # stem: 3 channels in a stage of 8 (masked filter tail), ragged tiles
@@ -792,6 +834,16 @@ def test_merge_detections_device(golden_dir, dev):
         if name in z and name != "random40":
             assert set(map(tuple, got.tolist())) == set(map(tuple, z[name].reshape(-1, 7).tolist())), name
     assert out_count[names.index("clusters1")] < 1024 and out_count[names.index("clusters3")] == 0
+    assert not out[names.index("clusters3")].any()      # rows past an image's count read as zeros, not as uninitialised memory
+    # the list form detect(merge_boxes=True, merge_on_device=True) goes through: the same rows, None for an image without detections
+    from amyloid_yolo_paper_amd.postprocess import merge_detections_batch_device
+    dets = [None if len(cases[nm]) == 0 else torch.from_numpy(cases[nm]) for nm in names]
+    got_list = merge_detections_batch_device(dets)
+    for b, nm in enumerate(names):
+        if len(cases[nm]) == 0:
+            assert got_list[b] is None
+        else:
+            np.testing.assert_array_equal(got_list[b].numpy(), out[b, :out_count[b]], err_msg=nm)
 
 
 def test_giou_closed_form_vectors_hip(golden_dir):
