@@ -226,6 +226,17 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
     constexpr int IN_W = (TW - 1) * STRIDE + KS;
     constexpr int IN_PIX = IN_H * IN_W;
     constexpr int PX_PIECES = (2 * IN_PIX + 63) / 64;       // 1-KiB DMA pieces per 16-channel pixel slab
+    // Stride 2: the LDS image of a halo row keeps even and odd input columns apart -- [even cols, half 0 | even, half 1 | odd, half 0 |
+    // odd, half 1], 2 IN_W cells per row -- so that the 32 pixels of a fragment read, which lie two columns apart, are CONSECUTIVE
+    // 16-byte cells (conflict-free ds_read_b128, as the stride-1 image is); with the plain [half][pixel] image they sit 32 bytes apart
+    // and every pixel-fragment read is a 2-way bank conflict (SQ_LDS_BANK_CONFLICT = 0.32 of SQ_LDS_IDX_ACTIVE on these layers,
+    // profiles/r04_pmc_sq_v1.txt).  A DMA piece still covers both halves of its pixels, so the global side fetches the same lines
+    // with the same number of requests.  -DAY_S2_DEINT=0 restores the plain image.
+#ifndef AY_S2_DEINT
+#define AY_S2_DEINT 1
+#endif
+    constexpr bool S2L = (STRIDE == 2 && KS == 3 && AY_S2_DEINT);
+    constexpr int NEV = TW + 1;                             // even columns of a stride-2 halo row (IN_W = 2 TW + 1)
     constexpr int PIX_SLAB = PX_PIECES * 1024;
     constexpr int W_PIECES = KK2 * 2 * BN * 16 / 1024;      // per 16-channel filter slab
     constexpr int W_SLAB = W_PIECES * 1024;
@@ -357,8 +368,16 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
             if (i < PWP) {
                 const int q = i * 8 + wave;  // pixel piece; q >= NK * PX_PIECES: padding
                 const int kk = q / PX_PIECES, j = q % PX_PIECES;
-                const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX]
-                const int h = u / IN_PIX, P = u % IN_PIX;
+                const int u = j * 64 + lane;           // unit inside the slab, LDS order [half][IN_PIX] (S2L: see above)
+                int h = u / IN_PIX, P = u % IN_PIX;
+                if constexpr (S2L) {
+                    const int r = u / (2 * IN_W), v = u % (2 * IN_W);
+                    const bool ev = v < 2 * NEV;
+                    const int w2 = ev ? v : v - 2 * NEV;
+                    const int per = ev ? NEV : TW;
+                    h = r < IN_H ? w2 / per : 2;       // units past the image: padding of the piece list
+                    P = r * IN_W + 2 * (w2 % per) + (ev ? 0 : 1);
+                }
                 int iy = y0 * STRIDE - PAD + P / IN_W;
                 int ix = x0 * STRIDE - PAD + P % IN_W;
                 bool inside = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
@@ -430,12 +449,16 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
         advance_loader();
     };
 
-    int pb[NT];
+    int pb[NT], pbo[S2L ? NT : 1];   // pbo (S2L): the odd-column cells (kw = 1)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int p = (wn * NT + n) * 32 + c;
         const int ty = p / TW, tx = p % TW;
         pb[n] = (hh * IN_PIX + ty * STRIDE * IN_W + tx * STRIDE) * 16;
+        if constexpr (S2L) {
+            pb[n] = (ty * 2 * (2 * IN_W) + hh * NEV + tx) * 16;
+            pbo[n] = (ty * 2 * (2 * IN_W) + 2 * NEV + hh * TW + tx) * 16;
+        }
     }
     const int wa = W_BASE + (hh * BN + wm * MT * 32 + c) * 16;
     const int nstages = a.cin / (16 * NK);
@@ -511,8 +534,12 @@ __global__ void __launch_bounds__(512, 2) conv_bf16_ring_kernel(ConvArgs a, int 
                 for (int m = 0; m < MT; ++m)
                     fa[m] = *reinterpret_cast<const vec8*>(L + wa + kk * W_SLAB + (tap * 2 * BN + m * 32) * 16);
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    fb[n] = *reinterpret_cast<const vec8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (S2L)   // row kh of the halo: 2 IN_W cells further on; kw = 0 / 2: even cells tx / tx + 1, kw = 1: odd cell tx
+                        fb[n] = *reinterpret_cast<const vec8*>(L + kk * PIX_SLAB + (kw == 1 ? pbo[n] : pb[n]) + (kh * 2 * IN_W + (kw == 2 ? 1 : 0)) * 16);
+                    else
+                        fb[n] = *reinterpret_cast<const vec8*>(L + kk * PIX_SLAB + pb[n] + (kh * IN_W + kw) * 16);
+                }
             };
             if (!AY_DBGBIT(a, 2)) load_frags(0, af[0], bfr[0]);
 #pragma unroll
