@@ -13,6 +13,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes several seconds (still part of -m 'not gpu')")
 
 
 @pytest.fixture(scope="session")

@@ -34,6 +34,49 @@ def _model(C_, cfg_dir):
     return m
 
 
+GRAD_LAYERS = (0, 1, 2, 42, 73, 80, 81, 93, 104, 105)
+_SPREAD = {}
+
+
+def _trimmed_rel_l2(g, ref, keep=0.98):
+    """relative L2 over the `keep` share of the elements with the smallest error: a LeakyReLU sign flip moves one filter row (0.1 % of
+    a layer) by a lot and everything else by a little; a systematic error of a kernel moves every element"""
+    e = np.abs(np.asarray(g, np.float64) - np.asarray(ref, np.float64)).reshape(-1)
+    k = max(1, int(keep * e.size))
+    idx = np.argpartition(e, k - 1)[:k]
+    return float(np.linalg.norm(e[idx]) / max(np.linalg.norm(np.asarray(ref, np.float64).reshape(-1)[idx]), 1e-30))
+
+
+def _contract_spread(tmp_cfg_dir):
+    """What the fp32 contract itself leaves open, measured on the CPU oracle: the training step of every TRAIN_CASE evaluated twice --
+    convolution sums in fp32 (ATen's order, = the reference) and in float64 -- and, per checked layer, the trimmed relative L2
+    distance of the two filter gradients; the maximum over the cases (a flip is a chance event of a case) and, walking from the
+    loss down, over the layers above (a layer's gradient carries every flip between it and the loss).  The HIP step is a third
+    evaluation of the same contract in yet another summation order: it is held to a small multiple of this spread."""
+    if _SPREAD:
+        return _SPREAD
+    from oracle.darknet_oracle import OracleDarknet
+    per_layer = {li: 0.0 for li in GRAD_LAYERS}
+    for name, C_, S, B, seed in gc.TRAIN_CASES:
+        grads = []
+        for f64 in (False, True):
+            cfg = cfg_gen.write_cfg(C_, tmp_cfg_dir)
+            o = OracleDarknet(cfg)
+            o.set_params(synth.synth_params(parse_config.parse_model_config(cfg), seed=7))
+            o.conv_f64 = f64
+            o.require_grad()
+            loss, _ = o.forward(torch.from_numpy(gc.model_inputs(S, B, 10)), torch.from_numpy(gc.train_targets(B, C_, S, seed)), train_bn=True)
+            loss.backward()
+            grads.append({li: o.params[li]["weight"].grad.numpy() for li in GRAD_LAYERS})
+        for li in GRAD_LAYERS:
+            per_layer[li] = max(per_layer[li], _trimmed_rel_l2(grads[0][li], grads[1][li]))
+    run = 0.0
+    for li in sorted(GRAD_LAYERS, reverse=True):
+        run = max(run, per_layer[li])
+        _SPREAD[li] = run
+    return _SPREAD
+
+
 @pytest.mark.parametrize("case", gc.TRAIN_CASES, ids=lambda c: c[0])
 def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
     """loss within 1e-4, the 13 per-layer metrics within 2e-4, sampled gradients within 2e-3 of the layer's gradient
@@ -61,7 +104,12 @@ def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
     # Each flip changes dz at one element by up to 10x and spreads from there, so those layers are held to
     # 10 % of the gradient scale element-wise (one flipped sample of 32 moves a whole filter row) and 3 % in relative L2; the kernels themselves are pinned tightly,
     # one by one, in test_backward_kernels_vs_autograd below.
-    def check_grad(g, ref, tight, what):
+    # On top of those flip allowances every filter gradient is held, in TRIMMED relative L2 (the 2 % of the elements with the largest
+    # error left out: the flipped rows), to 2.5x what the contract itself leaves open at that depth (_contract_spread: 3e-5 at layer
+    # 80, 0.4 % at 73, 0.8 % from 42 down) -- a kernel that is 2 % off in a deep layer fails this, where the flat 3 % let it pass.
+    spread = _contract_spread(tmp_cfg_dir)
+
+    def check_grad(g, ref, tight, what, trimmed_bar=None):
         g, ref = np.asarray(g, np.float64), np.asarray(ref, np.float64)
         scale = max(np.abs(ref).max(), 1e-12)
         if tight:
@@ -69,15 +117,19 @@ def test_train_step_vs_reference(golden_dir, tmp_cfg_dir, case):
         else:
             assert np.abs(g - ref).max() <= 1e-1 * scale, (what, float(np.abs(g - ref).max() / scale))
             assert np.linalg.norm(g - ref) <= 3e-2 * np.linalg.norm(ref), (what, float(np.linalg.norm(g - ref) / np.linalg.norm(ref)))
+        if trimmed_bar is not None:
+            t = _trimmed_rel_l2(g, ref)
+            print(f"{what}: trimmed rel L2 {t:.2e} (bar {trimmed_bar:.2e}), rel L2 {np.linalg.norm(g - ref) / np.linalg.norm(ref):.2e}")
+            assert t <= trimmed_bar, (what, t, trimmed_bar)
 
-    for li in (0, 1, 2, 42, 73, 80, 81, 93, 104, 105):
+    for li in GRAD_LAYERS:
         conv = m.module_list[li][0]
         g = conv.weight.grad.cpu().numpy()
         ref = z[f"gw{li}"]
         if ref.shape != g.shape:
             g = g.reshape(-1)[:: max(1, g.size // 65536)]
         tight = li in (81, 93, 105)
-        check_grad(g, ref, tight, f"dW{li}")
+        check_grad(g, ref, tight, f"dW{li}", trimmed_bar=max(2.5 * spread[li], 2e-4))
         if conv.bias is not None:
             check_grad(conv.bias.grad.cpu().numpy(), z[f"gb{li}"], tight, f"db{li}")
         else:

@@ -71,14 +71,19 @@ def _oracle_model(C, cfg_dir):
     return m, defs
 
 
-@pytest.mark.parametrize("case", [c for c in gc.MODEL_CASES if c[2] <= 416], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [c if c[2] <= 416 else pytest.param(c, marks=pytest.mark.slow) for c in gc.MODEL_CASES], ids=lambda c: c[0])
 def test_model_forward(golden_dir, tmp_cfg_dir, case):
+    """every whole-model fixture of the reference, the 1024^2 one included (marked slow: a few seconds of CPU convolutions), so that
+    the fixture the GPU tests of BASELINE configs[1] lean on pins the oracle too"""
     name, C, S, B, start = case
     z = load(golden_dir, "model_" + name)
     m, _ = _oracle_model(C, tmp_cfg_dir)
     with torch.no_grad():
         out = m.forward(torch.from_numpy(gc.model_inputs(S, B, start)), collect=True).numpy()
-    close(out, z["out"])
+    if "out" in z:
+        close(out, z["out"])
+    else:   # the 1024^2 fixture stores 256 sampled decode rows instead of all 64 512
+        close(out[:, z["out_rows"]], z["out_sel"])
     for k, li in enumerate(z["layer_idx"]):
         f = m.layer_outputs[int(li)].numpy().reshape(-1)
         close(f[z["samp_idx"][k]], z["samp_val"][k])
