@@ -51,6 +51,8 @@ _SIGS = {
     "ay_conv_fwd_f32": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ay_conv_fwd_f32_valu": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ay_yolo_decode": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _P]),
+    "ay_head_decode_fwd_bf16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _I, _P]),
+    "ay_head_decode_fwd_f16": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _I, _P]),
     "ay_xywh2xyxy": (_I, [_P, _I64, _I, _P]),
     "ay_box_iou": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "ay_box_iou_pairwise": (_I, [_P, _I, _P, _I, _I, _P, _P]),

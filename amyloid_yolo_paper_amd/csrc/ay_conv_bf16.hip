@@ -25,8 +25,8 @@
 
 namespace ay {
 
-template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES, typename DT = Bf16>
-__global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
+template <int KS, int STRIDE, int BN, int WM, int WN, int TH, int TW, int NK, bool OUT_F32, bool HAS_RES, typename DT = Bf16, bool DECODE = false>
+__global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a, DecodeArgs dd) {
     DT::enter();
     typedef typename DT::vec8 vec8;
     constexpr int PAD = (KS - 1) / 2;
@@ -182,9 +182,13 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(ConvArgs a) {
         }
     }
 
-    ResRegs<MT, NT> rr;
-    residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
-    conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES, false, 0, false, false, DT>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+    if constexpr (DECODE) {   // a detection head: the prediction rows instead of a head tensor
+        head_decode_epilogue<BN, MT, NT, TW>(a, dd, acc, b, cg, wm, wn, c, hh, y0, x0);
+    } else {
+        ResRegs<MT, NT> rr;
+        residual_prefetch<BN, MT, NT, TW, HAS_RES>(a, rr, b, cg, wm, wn, c, hh, y0, x0);
+        conv_epilogue<BN, MT, NT, TW, OUT_F32, HAS_RES, false, 0, false, false, DT>(a, acc, rr, b, cg, wm, wn, c, hh, y0, x0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -772,12 +776,12 @@ static int launch(const ay_conv_desc* d, const void* src, const void* w, const f
     } else {
         dim3 grid((unsigned)nblk), block(256);
         if constexpr (OUT_F32) {
-            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false, DT>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, true, false, DT>), grid, block, 0, st, a, DecodeArgs{});
         } else {
             if (residual)
-                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true, DT>), grid, block, 0, st, a);
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, true, DT>), grid, block, 0, st, a, DecodeArgs{});
             else
-                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false, DT>), grid, block, 0, st, a);
+                hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, BN, WM, WN, TH, TW, NK, false, false, DT>), grid, block, 0, st, a, DecodeArgs{});
         }
     }
     AY_CHECK_LAUNCH("conv_bf16_kernel");
@@ -989,6 +993,53 @@ static int conv_fwd_16(const ay_conv_desc* d, const void* src, const void* w_pac
     return launch<1, 1, 32, 1, 4, 8, 32, 1, false, false, DT>(d, src, w_packed, scale, shift, residual, out, st);
 }
 }  // namespace ay
+
+namespace ay {
+// A detection head with its decode: the linear 1x1 convolution of models.py:33-40 (heads 81 / 93 / 105: bias, no BatchNorm, no
+// activation) through conv_bf16_kernel<..., DECODE>, whose epilogue writes rows [row_offset, row_offset + A G G) of pred.
+template <typename DT>
+static int head_decode_fwd(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                           int num_anchors, int num_classes, int img_dim, const float* anchors_wh, float* pred, int n_total,
+                           int row_offset, ay_stream_t stream) {
+    AY_CHECK_ARG(d && src && w_packed && scale && shift && anchors_wh && pred, "ay_head_decode_fwd: null argument");
+    AY_CHECK_ARG(d->ksize == 1 && d->stride == 1 && !d->leaky && d->cin % 16 == 0, "ay_head_decode_fwd: a linear 1x1 block (cin %% 16 == 0)");
+    AY_CHECK_ARG(d->hout == d->hin && d->wout == d->win && d->hout == d->wout, "ay_head_decode_fwd: square grid, same size in and out");
+    const int K = 5 + num_classes;
+    AY_CHECK_ARG(num_anchors >= 1 && num_anchors <= 6 && num_classes >= 1 && num_anchors * K == d->cout && d->cout_pad == (d->cout + 31) / 32 * 32,
+                 "ay_head_decode_fwd: %d anchors x (5 + %d classes) != %d filters (padded %d)", num_anchors, num_classes, d->cout, d->cout_pad);
+    AY_CHECK_ARG(row_offset >= 0 && row_offset + num_anchors * d->hout * d->wout <= n_total, "ay_head_decode_fwd: rows out of range");
+    ConvArgs a;
+    fill_args(a, d, src, w_packed, scale, shift, nullptr, nullptr, 8, 32, 32);
+    DecodeArgs dd{};
+    dd.pred = pred;
+    dd.n_total = n_total;
+    dd.row_offset = row_offset;
+    dd.A = num_anchors;
+    dd.K = K;
+    dd.stride = (float)((double)img_dim / (double)d->hout);   // Python float division, then cast (models.py:119): as ay_yolo_decode
+    for (int i = 0; i < num_anchors; ++i) dd.aw[i] = anchors_wh[2 * i], dd.ah[i] = anchors_wh[2 * i + 1];
+    const long long nblk = (long long)a.tiles_x * a.tiles_y * d->batch * a.n_cgroups;
+    AY_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffLL, "ay_head_decode_fwd: grid out of range");
+    dim3 grid((unsigned)nblk), block(256);
+    if (d->cin % 64 == 0)
+        hipLaunchKernelGGL((conv_bf16_kernel<1, 1, 32, 1, 4, 8, 32, 4, true, false, DT, true>), grid, block, 0, S(stream), a, dd);
+    else
+        hipLaunchKernelGGL((conv_bf16_kernel<1, 1, 32, 1, 4, 8, 32, 1, true, false, DT, true>), grid, block, 0, S(stream), a, dd);
+    AY_CHECK_LAUNCH("conv_bf16_kernel<DECODE>");
+    return AY_OK;
+}
+}  // namespace ay
+
+extern "C" int ay_head_decode_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                                       int num_anchors, int num_classes, int img_dim, const float* anchors_wh, float* pred, int n_total,
+                                       int row_offset, ay_stream_t stream) {
+    return ay::head_decode_fwd<ay::Bf16>(d, src, w_packed, scale, shift, num_anchors, num_classes, img_dim, anchors_wh, pred, n_total, row_offset, stream);
+}
+extern "C" int ay_head_decode_fwd_f16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale, const float* shift,
+                                      int num_anchors, int num_classes, int img_dim, const float* anchors_wh, float* pred, int n_total,
+                                      int row_offset, ay_stream_t stream) {
+    return ay::head_decode_fwd<ay::F16>(d, src, w_packed, scale, shift, num_anchors, num_classes, img_dim, anchors_wh, pred, n_total, row_offset, stream);
+}
 
 extern "C" int ay_conv_fwd_bf16(const ay_conv_desc* d, const void* src, const void* w_packed, const float* scale,
                                 const float* shift, const void* residual, void* out, ay_stream_t stream) {

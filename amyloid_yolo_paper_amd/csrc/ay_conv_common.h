@@ -41,6 +41,17 @@ struct ConvArgs {
     unsigned w_class_stride;
 };
 
+// Fused YOLO decode of a detection head (ay_head_decode_fwd_*: models.py:127-172 applied in the epilogue of the head's 1x1
+// convolution, conv_bf16_kernel<..., DECODE>): where the prediction rows go and what the decode needs.  Empty for every other launch.
+struct DecodeArgs {
+    float* pred;        // [B][n_total][K] float32
+    int n_total;        // rows per image
+    int row_offset;     // first row of this head
+    int A, K;           // anchors of the head, 5 + classes
+    float stride;       // img_dim / G as the reference computes it (models.py:119)
+    float aw[6], ah[6]; // anchors in pixels
+};
+
 // canvas pixel -> image pixel; false: gutter / beyond the batch (reads as zero, is never stored)
 __device__ __forceinline__ bool canvas_px(const ConvArgs& a, int cy, int cx, int& b, int& y, int& x) {
     const int H1 = a.hout + 1, W1 = a.wout + 1;
@@ -307,6 +318,59 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp)
                     __builtin_amdgcn_raw_buffer_store_b128(outv[n * MT + m][qp], orsrc, vo + (unsigned)((chf + qp * 16) >> 4) * plane_bytes, 0, 0);
+            }
+        }
+    }
+}
+
+// Epilogue of a detection head with the decode fused in: the linear 1x1 block's value (acc * scale + shift, as conv_epilogue forms
+// it; scale = 1, shift = the bias) never goes to memory as a head tensor -- each lane turns the values it holds for its grid cell
+// straight into the entries of the prediction row (yolo_decode_kernel's expressions, operation for operation: the reference's
+// order, no contraction) and stores them.  A value is channel ch = anchor * K + k of the head; decoding it needs nothing but
+// itself, the cell and the anchor.  K == 8 (three classes): a lane's four consecutive channels are k = 0..3 or 4..7 of ONE anchor
+// -- one 16-byte store; other K: four scalar stores.
+template <int BN, int MT, int NT, int TW>
+__device__ __forceinline__ void head_decode_epilogue(const ConvArgs& a, const DecodeArgs& dd, f32x16 (&acc)[MT][NT], int b, int cg, int wm,
+                                                     int wn, int c, int hh, int y0, int x0) {
+    const int G = a.hout;
+    const float stride = dd.stride;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (wn * NT + n) * 32 + c;
+        const int oy = y0 + p / TW, ox = x0 + p % TW;
+        if (!(oy < a.hout && ox < a.wout)) continue;
+        float* rows = dd.pred + ((size_t)b * dd.n_total + dd.row_offset + (size_t)oy * G + ox) * dd.K;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {   // accumulator quad qd: channels ch0 .. ch0 + 3 of this lane
+                const int ch0 = cg * BN + (wm * MT + m) * 32 + qd * 8 + 4 * hh;
+                if (ch0 >= dd.A * dd.K) continue;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch0);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch0);
+                float res[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = ch0 + j;
+                    const int an = ch / dd.K, k = ch - an * dd.K;
+                    const float v = acc[m][n][qd * 4 + j] * sc[j] + sh[j];
+                    const bool wh = (k == 2) || (k == 3);
+                    const float e = expf(wh ? v : -v);
+                    const float sig = 1.0f / (1.0f + e);
+                    const float anc = (k == 2 ? dd.aw[an < 6 ? an : 0] : dd.ah[an < 6 ? an : 0]) / stride;
+                    res[j] = k == 0 ? (sig + (float)ox) * stride : k == 1 ? (sig + (float)oy) * stride : wh ? (e * anc) * stride : sig;
+                }
+                if (dd.K == 8) {   // channels ch0..ch0+3 = entries 4hh'..4hh'+3 of anchor ch0 / 8
+                    const int an = ch0 >> 3;
+                    *reinterpret_cast<float4*>(rows + (size_t)an * G * G * 8 + (ch0 & 7)) = make_float4(res[0], res[1], res[2], res[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = ch0 + j;
+                        const int an = ch / dd.K, k = ch - an * dd.K;
+                        if (ch < dd.A * dd.K) rows[(size_t)an * G * G * dd.K + k] = res[j];
+                    }
+                }
             }
         }
     }

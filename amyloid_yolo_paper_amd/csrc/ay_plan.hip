@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -21,6 +22,9 @@ struct ay_plan {
     size_t arena = 0;
     int img_dim = 0, n_total = 0;
     int dtype = AY_DT_BF16;  // storage type of activations and packed filters
+    // fused[i] = j > 0: op i is a detection head (linear 1x1 convolution into an fp32 value) whose only reader is the decode op j:
+    // issued as ONE ay_head_decode_fwd_* launch, the head value is never written; fused[j] = -1: issued with op i, skip
+    std::vector<int> fused;
     // profiling (ay_plan_profile_begin/end): one event list per recorded forward, a pair per selected op
     mutable bool profiling = false;
     mutable std::vector<std::vector<hipEvent_t>> prof_events;
@@ -40,9 +44,16 @@ void op_reads(const ay_plan_op& o, int (&r)[3]) {
     r[2] = o.kind == AY_OP_CONV ? o.res : AY_PLAN_NONE;
 }
 
-int issue(const ay_plan* p, const ay_plan_op& o, const float* x, uint8_t* ws, float* out, ay_stream_t st) {
+int issue(const ay_plan* p, size_t idx, const float* x, uint8_t* ws, float* out, ay_stream_t st) {
+    const ay_plan_op& o = p->ops[idx];
     auto at = [&](int v) -> void* { return v >= 0 ? ws + p->offset[v] : nullptr; };
     const ay_conv_desc& d = o.conv;
+    if (p->fused[idx] < 0) return AY_OK;   // a decode that went out with its head
+    if (p->fused[idx] > 0) {
+        const ay_plan_op& y = p->ops[p->fused[idx]];
+        return (p->dtype == AY_DT_F16 ? ay_head_decode_fwd_f16 : ay_head_decode_fwd_bf16)(
+            &d, at(o.src), o.w, o.scale, o.shift, y.num_anchors, y.num_classes, p->img_dim, y.anchors_wh, out, p->n_total, y.row_offset, st);
+    }
     if (p->dtype == AY_DT_F16) {
         switch (o.kind) {
             case AY_OP_STEM_S2_FUSED:
@@ -130,6 +141,19 @@ extern "C" int ay_plan_create(const ay_plan_op* ops, int n_ops, const size_t* va
         p->def_op[o.dst] = i;
         p->last_use[o.dst] = i;
     }
+    // ---- detection heads: a linear 1x1 convolution into an fp32 value read by the NEXT op, a decode, and by nothing else ----------
+    p->fused.assign(n_ops, 0);
+    static const int fuse_heads = getenv("AY_FUSE_HEAD") ? atoi(getenv("AY_FUSE_HEAD")) : 1;
+    for (int i = 0; fuse_heads && i + 1 < n_ops; ++i) {
+        const ay_plan_op& o = p->ops[i];
+        const ay_plan_op& y = p->ops[i + 1];
+        if (o.kind == AY_OP_CONV && o.conv.out_f32 && o.conv.ksize == 1 && o.conv.stride == 1 && !o.conv.leaky && o.res == AY_PLAN_NONE &&
+            y.kind == AY_OP_DECODE && y.src == o.dst && p->last_use[o.dst] == i + 1 && o.conv.hout == o.conv.wout && y.grid == o.conv.hout &&
+            y.num_anchors * (5 + y.num_classes) == o.conv.cout && o.conv.cout_pad == (o.conv.cout + 31) / 32 * 32) {
+            p->fused[i] = i + 1;
+            p->fused[i + 1] = -1;
+        }
+    }
     // ---- arena: first fit over lifetimes, in definition order ------------------------------------------------------
     struct Live {
         size_t off, size;
@@ -184,7 +208,7 @@ extern "C" int ay_plan_forward(const ay_plan* plan, const float* x_nchw, void* w
             }
             (void)hipEventRecord((*ev)[2 * i], st);
         }
-        const int rc = issue(plan, plan->ops[i], x_nchw, static_cast<uint8_t*>(workspace), out_rows, stream);
+        const int rc = issue(plan, i, x_nchw, static_cast<uint8_t*>(workspace), out_rows, stream);
         if (rc != AY_OK) return rc;  // the entry point has set the message
         if (timed) (void)hipEventRecord((*ev)[2 * i + 1], st);
     }
@@ -233,7 +257,7 @@ extern "C" int ay_plan_forward_timed(const ay_plan* plan, const float* x_nchw, v
         if (hipEventCreate(&e) != hipSuccess) rc = AY_ERR_LAUNCH;
     if (rc == AY_OK && hipEventRecord(ev[0], st) != hipSuccess) rc = AY_ERR_LAUNCH;
     for (size_t i = 0; i < n && rc == AY_OK; ++i) {
-        rc = issue(plan, plan->ops[i], x_nchw, static_cast<uint8_t*>(workspace), out_rows, stream);
+        rc = issue(plan, i, x_nchw, static_cast<uint8_t*>(workspace), out_rows, stream);
         if (rc == AY_OK && hipEventRecord(ev[i + 1], st) != hipSuccess) rc = AY_ERR_LAUNCH;
     }
     if (rc == AY_OK && hipStreamSynchronize(st) != hipSuccess) rc = AY_ERR_LAUNCH;

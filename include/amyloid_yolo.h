@@ -172,6 +172,17 @@ int ay_conv_fwd_f32_valu(const ay_conv_desc* d, const float* src1, int cin1, int
 int ay_yolo_decode(const float* head, int layout, float* out, int batch, int num_anchors, int num_classes,
                    int grid, int img_dim, const float* anchors_wh /* host, A*2, pixels */, int n_total,
                    int row_offset, ay_stream_t stream);
+/* A detection head AND its decode in one launch (models.py:33-40 for the linear 1x1 head convolution 81 / 93 / 105, then
+ * models.py:127-172): the head tensor never goes to memory, the convolution's epilogue writes rows [row_offset, row_offset + A*G*G)
+ * of pred [B][n_total][5+C] -- the same bits ay_conv_fwd_bf16 (out_f32) + ay_yolo_decode produce.  d: ksize 1, stride 1, leaky 0,
+ * cout = A*(5+C), cout_pad = cout rounded up to 32; scale = ones, shift = the bias (ay_fold_bn without BatchNorm). */
+int ay_head_decode_fwd_bf16(const ay_conv_desc* d, const void* src_blocked_bf16, const void* w_packed, const float* scale,
+                            const float* shift, int num_anchors, int num_classes, int img_dim,
+                            const float* anchors_wh /* host, A*2, pixels */, float* pred, int n_total, int row_offset,
+                            ay_stream_t stream);
+int ay_head_decode_fwd_f16(const ay_conv_desc* d, const void* src_blocked_f16, const void* w_packed, const float* scale,
+                           const float* shift, int num_anchors, int num_classes, int img_dim, const float* anchors_wh, float* pred,
+                           int n_total, int row_offset, ay_stream_t stream);
 
 /* ---- box math: utils/utils.py:53-59,193-232 ---------------------------------------------------- */
 int ay_xywh2xyxy(float* boxes, int64_t n_rows, int row_stride, ay_stream_t stream); /* in place, first 4 cols */

@@ -88,6 +88,48 @@ def test_decode_kat_and_heads(golden_dir, dev):
     close(out.cpu().numpy(), zz["out"], 1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [(256, 3, 3, 40, 2), (512, 3, 2, 13, 3), (80, 3, 3, 9, 2), (128, 3, 80, 20, 1), (64, 2, 1, 33, 2)],
+                         ids=lambda c: "cin%d_A%d_C%d_G%d_B%d" % c)
+def test_head_decode_fused_equals_head_then_decode(dev, case, dtype):
+    """ay_head_decode_fwd_* (the detection head's linear 1x1 convolution with the decode of models.py:127-172 in its epilogue; what the
+    native plan issues for layers 81+82 / 93+94 / 105+106) against the two launches it replaces, ay_conv_fwd_* (out_f32) +
+    ay_yolo_decode: the same bits, for 5 + C = 8 (16-byte row stores), 7, 6 and 85 (scalar stores, several 32-channel groups), both
+    staging depths (cin % 64), ragged grids, rows of other heads left untouched."""
+    cin, A, Cn, G, B = case
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    K = 5 + Cn
+    cout = A * K
+    cpad = (cout + 31) // 32 * 32
+    g = torch.Generator().manual_seed(cin + 13 * K + G)
+    x = torch.randn(B, cin, G, G, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.5 / np.sqrt(cin))
+    bias = torch.randn(cout, generator=g)
+    xd, wd = x.to(dev), w.to(dev)
+    xb = torch.empty(B, cin // 16, G, G, 16, device=dev, dtype=tdt)
+    check(getattr(L, f"ay_nchw_f32_to_blocked_{dtype}")(ptr(xd), ptr(xb), B, cin, G, G, st))
+    packed = torch.empty(L.ay_packed_weight_bytes(cpad, cin, 1), device=dev, dtype=torch.uint8)
+    check(getattr(L, f"ay_pack_conv_weights_{dtype}")(ptr(wd), ptr(packed), cout, cpad, cin, 1, st))
+    sc, sh = torch.zeros(cpad, device=dev), torch.zeros(cpad, device=dev)
+    sc[:cout], sh[:cout] = 1.0, bias.to(dev)
+    anchors = [(10.0, 13.0), (16.0, 30.0), (33.0, 23.0), (30.0, 61.0)][:A]
+    anc = (C.c_float * (2 * A))(*[v for a in anchors for v in a])
+    img = 32 * G
+    n_total = A * G * G + 7
+    d = ConvDesc(B, cin, cout, G, G, G, G, 1, 1, 0, 1, cpad)
+    head = torch.empty(B, cpad // 16, G, G, 16, device=dev, dtype=torch.float32)
+    want = torch.full((B, n_total, K), -7.0, device=dev)
+    check(getattr(L, f"ay_conv_fwd_{dtype}")(C.byref(d), ptr(xb), ptr(packed), ptr(sc), ptr(sh), None, ptr(head), st), "head conv")
+    check(L.ay_yolo_decode(ptr(head), 1, ptr(want), B, A, Cn, G, img, anc, n_total, 5, st), "decode")
+    got = torch.full((B, n_total, K), -7.0, device=dev)
+    check(getattr(L, f"ay_head_decode_fwd_{dtype}")(C.byref(d), ptr(xb), ptr(packed), ptr(sc), ptr(sh), A, Cn, img, anc, ptr(got), n_total, 5, st),
+          "fused head")
+    assert torch.equal(got, want)
+    assert bool((got[:, :5] == -7.0).all()) and bool((got[:, 5 + A * G * G:] == -7.0).all()) and bool(torch.isfinite(got[:, 5:5 + A * G * G]).all())
+
+
 # ----------------------------------------------------------------------------------------- NMS
 @pytest.mark.parametrize("name", [c[0] for c in gc.NMS_CASES])
 def test_nms_golden(golden_dir, dev, name):
