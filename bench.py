@@ -161,6 +161,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py (rank {rank} of {world}) needs a HIP device: no CPU fallback for the product path")
+    if os.environ.get("AY_BENCH_SHARE_GPU"):   # rehearsal of the N-rank launch on a box with fewer GPUs than ranks: ranks share devices
+        local_rank %= torch.cuda.device_count()  # (gloo legs only: RCCL refuses two ranks on one device, so pass --no_train_leg)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # AY_FORCE_DIST=1 walks the process-group code path with a single rank too (rehearsal of the N>1 launch on a 1-GPU box)
@@ -349,7 +351,9 @@ def main():
         group = None
         try:
             if USE_DIST:
-                group = dist.new_group(backend="nccl", device_id=dev)
+                import datetime
+                # a rank that fails alone (e.g. out of memory) must not leave the others waiting in a collective for ever
+                group = dist.new_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
             tr = measure_train(a, rank, world, dev, a.train_batch, a.leg_train_size, a.leg_train_steps, 2, group=group)
             result["train"] = {k: tr[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
                                                     "all_reduce_bytes", "all_reduce_buckets", "roofline") if k in tr}
