@@ -147,7 +147,7 @@ def test_configs2_train_b32_100_steps():
     """BASELINE.json configs[2]: random-init YOLOv3 (3 classes), batch 32, synthetic boxes, 100 optimiser steps on the bf16 MFMA
     path with the step bench.py --mode train times (flat gradient buffer, ay_adam_flat): every loss finite, the loss falls
     (mean of the last 10 steps below a third of the first), filters are re-packed once per step, and the step's memory stays
-    bounded -- at 1024^2 (10 steps) below 60 GB (round 1 peaked at ~219 GB through per-step allocations)."""
+    bounded -- at 1024^2 (100 steps too) below 60 GB (round 1 peaked at ~219 GB through per-step allocations)."""
     from amyloid_yolo_paper_amd import cfg_gen, synth
     from amyloid_yolo_paper_amd.models import Darknet
     from amyloid_yolo_paper_amd.parallel import FlatAdam, FlatGradReducer
@@ -160,7 +160,7 @@ def test_configs2_train_b32_100_steps():
     model.collect_metrics = False
     red = FlatGradReducer(model.parameters(), n_buckets=4).attach(model)
     opt = FlatAdam(red)
-    for S, steps in ((416, 100), (1024, 10)):
+    for S, steps in ((416, 100), (1024, 100)):   # configs[2] as written: 100 optimiser steps at B=32, at the reference's 416 AND at 1024^2
         B = 32
         x = torch.from_numpy(synth.synth_tiles(8, S, start=100)).to(dev).repeat(4, 1, 1, 1).contiguous()
         tg = torch.from_numpy(synth.synth_targets(B, 3, seed=77, grid=S // 8)).to(dev)
@@ -176,10 +176,10 @@ def test_configs2_train_b32_100_steps():
             losses.append(loss)
         lv = np.array([float(v.item()) for v in losses])
         assert np.isfinite(lv).all(), lv
-        if steps >= 100:
+        if S == 416:      # from the random init
             assert lv[-10:].mean() < lv[0] / 3.0, (lv[0], lv[-10:].mean())
-        else:
-            assert lv[-1] < lv[0], (lv[0], lv[-1])
+        else:             # the same model and optimiser state carried on at the larger size: keeps falling
+            assert lv[-10:].mean() < lv[:10].mean(), (lv[:10].mean(), lv[-10:].mean())
         peak = torch.cuda.max_memory_allocated() / 1e9
         print(f"configs[2] S={S}: loss {lv[0]:.1f} -> {lv[-1]:.1f}, peak HBM {peak:.1f} GB")
         if S == 1024:
