@@ -57,7 +57,7 @@ __device__ unsigned long long g_wgrad_ticks[8];
 // ~1.4 us with one or two waves multiplying), and the small tile's ring is half the size, so two workgroups share a CU and twice
 // the segments are in flight.
 template <int KS, int STRIDE, int SEGS = 1, int NBUF = 4, int CO_PL = 8, int CI_PL = 4>
-__global__ void __launch_bounds__(512, (CO_PL * CI_PL == 32 ? 2 : 4)) wgrad_bf16_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(512, (CO_PL * CI_PL >= 32 ? 2 : 4)) wgrad_bf16_kernel(WgradArgs a) {
     constexpr int PAD = (KS - 1) / 2;
     constexpr int KK2 = KS * KS;
     constexpr int COW = CO_PL * CI_PL / 8;              // co planes per wave: 8 waves = (CO_PL / COW) x CI_PL
@@ -372,6 +372,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 constexpr int WGRAD_SEGS_1X1 = 4;
+#ifndef AY_WGRAD_WIDE_SEGS
+#define AY_WGRAD_WIDE_SEGS 2
+#endif
+constexpr int WGRAD_SEGS_1X1_WIDE = AY_WGRAD_WIDE_SEGS;                     // the 128 x 128 tile of the 1x1 layers: 16 KiB per segment,
+constexpr int WGRAD_NBUF_1X1_WIDE = 8 / AY_WGRAD_WIDE_SEGS;                 // 8 segment buffers (128 KiB) either way
 #ifndef AY_WGRAD_SEGS_3X3
 #define AY_WGRAD_SEGS_3X3 2
 #endif
@@ -386,15 +391,29 @@ static bool wgrad_narrow(const ay_conv_desc* d) {
     return on && (d->ksize == 3 ? (COP <= 4 && CIP <= 2) : (COP <= 2 && CIP <= 4));
 }
 
+// 1x1 layers with at least 128 x 128 filters: a 128 x 128 filter tile (8 x 8 planes, one ci plane and all 8 co planes per wave: 32
+// accumulator registers -- a 1x1 has one tap).  dz is then fetched once per 128 input channels instead of once per 64: the 1x1 weight
+// gradients are bound by their operand traffic, not by the matrix pipe (256->128 at 128^2, B=32: dz read by 4 ci blocks before).
+static bool wgrad_wide1x1(const ay_conv_desc* d) {
+    static const int on = getenv("AY_WGRAD_WIDE1") ? atoi(getenv("AY_WGRAD_WIDE1")) : 1;
+    const int CIP = (d->cin + 15) / 16;
+    const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
+    return on && d->ksize == 1 && COP >= 8 && CIP >= 8;
+}
+
 static long long wgrad_split(const ay_conv_desc* d, int* cob, int* cib, long long* total) {
     const int CIP = (d->cin + 15) / 16;
     const int COP = (d->cout_pad > 0 ? d->cout_pad : (d->cout + 15) / 16 * 16) / 16;
     *cob = (COP + 7) / 8;
     *cib = (CIP + 3) / 4;
+    if (wgrad_wide1x1(d)) *cib = (CIP + 7) / 8;
     const bool narrow = wgrad_narrow(d);
     if (narrow) *cob = *cib = 1;
     *total = (long long)d->batch * d->hout * ((d->wout + 31) / 32);
-    if (d->ksize == 1) *total = (*total + WGRAD_SEGS_1X1 - 1) / WGRAD_SEGS_1X1;   // K steps = groups of segments
+    if (d->ksize == 1) {   // K steps = groups of segments
+        const int sg = wgrad_wide1x1(d) ? WGRAD_SEGS_1X1_WIDE : WGRAD_SEGS_1X1;
+        *total = (*total + sg - 1) / sg;
+    }
     if (d->ksize == 3 && d->stride == 1) *total = (*total + WGRAD_SEGS_3X3 - 1) / WGRAD_SEGS_3X3;
     static const int wg_target = getenv("AY_WGRAD_WGS") ? atoi(getenv("AY_WGRAD_WGS")) : 256;
     long long ks = ((narrow ? 2 : 1) * wg_target + (long long)*cob * *cib - 1) / ((long long)*cob * *cib);   // ~1 workgroup per CU overall (narrow: 2) ...
@@ -474,7 +493,9 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
             hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2, 1, 4, 4, 2>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1, 3, 2, 4>), grid, block, 0, st, a);
-    } else if (d->ksize == 3 && d->stride == 1)
+    } else if (wgrad_wide1x1(d))
+        hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, WGRAD_SEGS_1X1_WIDE, WGRAD_NBUF_1X1_WIDE, 8, 8>), grid, block, 0, st, a);
+    else if (d->ksize == 3 && d->stride == 1)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 1, WGRAD_SEGS_3X3, WGRAD_NBUF_3X3>), grid, block, 0, st, a);
     else if (d->ksize == 3)
         hipLaunchKernelGGL((wgrad_bf16_kernel<3, 2>), grid, block, 0, st, a);
