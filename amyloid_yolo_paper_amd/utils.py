@@ -175,12 +175,10 @@ def graph_replay(graph):
     """Replay a captured `torch.cuda.CUDAGraph` of library calls on the current stream, followed by the library's stream fence
     (`ay_stream_fence`: an event owned by the library, recorded on the stream and waited for by the same stream; no host wait).
 
-    Round 2 attributed inconsistent replays to the runtime ("launches and stream / device synchronisation after hipGraphLaunch do
-    not wait for the graph").  Round 3 tested that claim in isolation (scripts/micro/graph_sync.hip, graph_coherence.hip: every
-    wait covers a replayed graph, and a kernel launched behind a replay sees all of its writes) and re-ran the unfenced test on the
-    current tree (static and dynamic item dealing, 4 of 4 runs equal to the eager step): the claim is withdrawn, the round-2 failures
-    are not reproduced (DESIGN.md section 4.1 keeps the record).  The fence stays as a stream-ordered no-op guard, now inside the
-    library instead of this helper."""
+    The fence is optional: a bare `graph.replay()` is the default form of the product test since round 4
+    (tests/test_gpu_configs.py::test_hip_graph_of_a_detection_step_replays_after_eager_steps; DESIGN.md section 4.1 holds the record
+    of the round-1/2 failures, the product fixes that predate every retained failing log, and the three isolating experiments that
+    cleared the runtime).  A captured step consists of this library's kernel nodes only."""
     graph.replay()
     check(_lib.lib().ay_stream_fence(_lib.stream_ptr()), "ay_stream_fence")
 

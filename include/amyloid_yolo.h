@@ -451,15 +451,14 @@ int ay_merge_detections_max_rows(void);
 int ay_merge_detections(const float* rows, const int* count, int batch, int max_rows, float* rows_out, int* count_out,
                         ay_stream_t stream);
 
-/* Replaying a captured HIP graph of these calls.  Every entry point is plain stream work (no allocation, no host copy, no
- * symbol access inside a call), so a stream capture of a step (ay_plan_forward + ay_nms_merge ...) replays like any other
- * graph; scripts/micro/graph_sync.hip and graph_coherence.hip show that on this runtime every wait covers a replayed graph and
- * a kernel launched behind a replay sees its writes.  The persistent kernels do rely on stream order between launches (a
- * launch hands its work-counter set back zeroed for a later launch on that stream, the plan's arena reuses a block once its
- * last reader has been issued): replay a graph on ONE stream at a time and do not run other library work on the capture
- * stream concurrently.  ay_stream_fence records a library-owned event on `stream` and makes the stream wait for it -- a
- * stream-ordered no-op on a healthy runtime that utils.graph_replay() places behind every replay: round 2 saw unfenced
- * replays return inconsistent steps on one pool host and fenced ones never (not reproduced since). */
+/* Replaying a captured HIP graph of these calls.  Every entry point is plain stream work -- kernel launches only: no allocation,
+ * no host copy, no memset node, no symbol access inside a call -- so a stream capture of a step (ay_plan_forward + ay_nms_merge ...)
+ * replays like any other graph (scripts/micro/graph_sync.hip, graph_coherence.hip, graph_input_coherence.hip: every wait covers a
+ * replayed graph, a kernel behind a replay sees its writes, a replay sees eager writes to its inputs).  The persistent kernels rely on
+ * stream order between launches (a launch hands its work-counter set back zeroed for a later launch on that stream, the plan's
+ * arena reuses a block once its last reader has been issued): replay a graph on ONE stream at a time and do not run other library
+ * work on the capture stream concurrently.  ay_stream_fence records a library-owned event on `stream` and makes the stream wait for
+ * it: an optional stream-ordered fence (utils.graph_replay() places it behind a replay; the product test replays without it). */
 int ay_stream_fence(ay_stream_t stream);
 
 #ifdef __cplusplus
