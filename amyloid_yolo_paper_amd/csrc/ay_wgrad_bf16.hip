@@ -350,25 +350,46 @@ __global__ void __launch_bounds__(512, (CO_PL * CI_PL >= 32 ? 2 : 4)) wgrad_bf16
 #endif
 }
 
-// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], s in ascending order: the same bits on every run.  Replaces ks x |dW| fp32
-// atomics (~1.3 TB/s chip-wide, 58 us of a 349-us launch at 128->256 3x3, B=32, 128^2) by plain stores + one streaming pass.
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i] in a FIXED order: the same bits on every run.  Replaces ks x |dW| fp32 atomics
+// (~1.3 TB/s chip-wide, 58 us of a 349-us launch at 128->256 3x3, B=32, 128^2) by plain stores + one streaming pass.
+// P lanes share one float4 of dW: lane part p sums the slabs p, p + P, p + 2P, ... in ascending order, the P partial sums are combined
+// by a butterfly over adjacent lanes (xor 1, 2, ...: a fixed tree).  With one lane per float4 a small filter (32 K floats = 32
+// workgroups) walked up to 128 slabs as one chain of dependent adds per thread: 74 launches at 25 us on average, 1.9 ms per step.
+template <int P>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, size_t n, int ks, int accumulate) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        float4 acc = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < ks; ++s) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int part = (int)(t & (P - 1));
+    const size_t i = (t / P) * 4;
+    const bool live = i + 4 <= n;   // n % 4 == 0 (host-checked)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        for (int s = part; s < ks; s += P) {
             const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * n + i);
             acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
         }
-        *reinterpret_cast<float4*>(dw + i) = acc;
-    } else {
-        for (size_t j = i; j < n; ++j) {
-            float acc = accumulate ? dw[j] : 0.f;
-            for (int s = 0; s < ks; ++s) acc += slab[(size_t)s * n + j];
-            dw[j] = acc;
-        }
     }
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1) {   // every lane of the wave takes part (dead lanes carry zeros)
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off);
+        acc.w += __shfl_xor(acc.w, off);
+    }
+    if (live && part == 0) {
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(dw + i);
+            acc.x += o.x, acc.y += o.y, acc.z += o.z, acc.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dw + i) = acc;
+    }
+}
+// any n (not a multiple of 4): one chain per element
+__global__ void __launch_bounds__(256) wgrad_reduce_scalar_kernel(const float* __restrict__ slab, float* __restrict__ dw, size_t n, int ks, int accumulate) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < ks; ++s) acc += slab[(size_t)s * n + j];
+    dw[j] = accumulate ? dw[j] + acc : acc;
 }
 
 constexpr int WGRAD_SEGS_1X1 = 4;
@@ -515,8 +536,25 @@ extern "C" int ay_conv_wgrad_bf16_ws(const ay_conv_desc* d, const void* x_blocke
     }
 #endif
     if (slabs) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_elems + 1023) / 1024)), dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks,
-                           accumulate);
+        if (dw_elems % 4) {
+            hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)((dw_elems + 255) / 256)), dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks,
+                               accumulate);
+        } else {   // lanes per float4: enough workgroups to fill the chip, no more parts than slabs
+            const size_t n4 = dw_elems / 4;
+            int P = n4 >= (size_t)256 * 1024 ? 4 : (n4 >= (size_t)64 * 1024 ? 8 : 16);
+            while (P > 1 && P > ks) P >>= 1;
+            const dim3 rg((unsigned)((n4 * P + 255) / 256));
+            if (P == 16)
+                hipLaunchKernelGGL(wgrad_reduce_kernel<16>, rg, dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks, accumulate);
+            else if (P == 8)
+                hipLaunchKernelGGL(wgrad_reduce_kernel<8>, rg, dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks, accumulate);
+            else if (P == 4)
+                hipLaunchKernelGGL(wgrad_reduce_kernel<4>, rg, dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks, accumulate);
+            else if (P == 2)
+                hipLaunchKernelGGL(wgrad_reduce_kernel<2>, rg, dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks, accumulate);
+            else
+                hipLaunchKernelGGL(wgrad_reduce_kernel<1>, rg, dim3(256), 0, st, a.slab, dw_oihw, dw_elems, (int)ks, accumulate);
+        }
         AY_CHECK_LAUNCH("wgrad_reduce_kernel");
     }
     return AY_OK;
