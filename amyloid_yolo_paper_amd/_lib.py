@@ -80,6 +80,7 @@ _SIGS = {
     "ay_plan_forward": (_I, [_P, _P, _P, _P, _P]),
     "ay_plan_forward_timed": (_I, [_P, _P, _P, _P, C.POINTER(C.c_float), _P]),
     "ay_plan_profile_begin": (_I, [_P, C.POINTER(C.c_ubyte)]),
+    "ay_plan_profile_begin_every": (_I, [_P, C.POINTER(C.c_ubyte), _I]),
     "ay_plan_profile_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ay_resblock_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ay_match_detections": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _P, _P]),

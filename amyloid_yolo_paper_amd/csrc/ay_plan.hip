@@ -27,6 +27,7 @@ struct ay_plan {
     std::vector<int> fused;
     // profiling (ay_plan_profile_begin/end): one event list per recorded forward, a pair per selected op
     mutable bool profiling = false;
+    mutable int prof_every = 1, prof_seen = 0;   // event pairs on every prof_every-th forward since ay_plan_profile_begin*
     mutable std::vector<std::vector<hipEvent_t>> prof_events;
     std::vector<unsigned char> prof_sel;
 };
@@ -195,7 +196,7 @@ extern "C" int ay_plan_forward(const ay_plan* plan, const float* x_nchw, void* w
     AY_CHECK_ARG(plan && x_nchw && workspace && out_rows, "ay_plan_forward: null argument");
     std::vector<hipEvent_t>* ev = nullptr;
     hipStream_t st = ay::S(stream);
-    if (plan->profiling) {  // stream-ordered event records only; elapsed times are read in ay_plan_profile_end
+    if (plan->profiling && (plan->prof_seen++ % plan->prof_every) == 0) {  // stream-ordered event records only; elapsed times are read in ay_plan_profile_end
         plan->prof_events.emplace_back(2 * plan->ops.size(), nullptr);
         ev = &plan->prof_events.back();
     }
@@ -215,13 +216,17 @@ extern "C" int ay_plan_forward(const ay_plan* plan, const float* x_nchw, void* w
     return AY_OK;
 }
 
-extern "C" int ay_plan_profile_begin(ay_plan* plan, const unsigned char* op_selected) {
-    AY_CHECK_ARG(plan && !plan->profiling, "ay_plan_profile_begin: null plan / already profiling");
+extern "C" int ay_plan_profile_begin_every(ay_plan* plan, const unsigned char* op_selected, int every) {
+    AY_CHECK_ARG(plan && !plan->profiling && every >= 1, "ay_plan_profile_begin: null plan / already profiling / every < 1");
     plan->prof_sel.assign(plan->ops.size(), 1);
     if (op_selected) plan->prof_sel.assign(op_selected, op_selected + plan->ops.size());
+    plan->prof_every = every;
+    plan->prof_seen = 0;
     plan->profiling = true;
     return AY_OK;
 }
+
+extern "C" int ay_plan_profile_begin(ay_plan* plan, const unsigned char* op_selected) { return ay_plan_profile_begin_every(plan, op_selected, 1); }
 
 extern "C" int ay_plan_profile_end(ay_plan* plan, float* op_ms_sum, int* n_forwards) {
     AY_CHECK_ARG(plan && plan->profiling && op_ms_sum && n_forwards, "ay_plan_profile_end: not profiling / null argument");

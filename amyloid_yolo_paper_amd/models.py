@@ -723,15 +723,15 @@ class Darknet(nn.Module):
             plans[key] = _Plan(handle, ws, ops, sum(vbytes))
         return plans[key]
 
-    def plan_profile_begin(self, B, S, layers=None):
+    def plan_profile_begin(self, B, S, layers=None, every=1):
         """start recording HIP event pairs around the ops of ``layers`` (conv layer indices; None = every op) in the plan of
-        this batch shape (bench.py: roofline of the 3x3 family)"""
+        this batch shape, on every ``every``-th forward (bench.py: roofline of the 3x3 family)"""
         dev = torch.device("cuda", torch.cuda.current_device())
         plan = self._plan(B, S, self._prepare(dev), dev)
         sel = None
         if layers is not None:
             sel = (C.c_ubyte * len(plan.ops))(*[int(getattr(o, "_layer", None) in layers) for o in plan.ops])
-        check(_lib.lib().ay_plan_profile_begin(plan.handle, sel), "ay_plan_profile_begin")
+        check(_lib.lib().ay_plan_profile_begin_every(plan.handle, sel, int(every)), "ay_plan_profile_begin")
 
     def plan_profile_end(self, B, S):
         """-> ([(layer index | None, op kind, ms summed over the recorded forwards)], number of forwards)"""

@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--cpu_tiles", type=int, default=16, help="tiles in the CPU-oracle sample (configs[0]: 16 tiles, ~12 s)")
     ap.add_argument("--serial_nms", action="store_true", help="run merge-NMS on the main stream (no overlap with the next batch)")
     ap.add_argument("--no_layer_events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--event_every", type=int, default=4,
+                    help="HIP event pairs around the dominant family's launches on every n-th step of the timed region (the first included): "
+                         "62 event records cost the 24-ms step 0.17 ms when every step carries them (same-box A/B)")
     ap.add_argument("--launch_probe", action="store_true",
                     help="rank plumbing only (no GPU): every rank joins the gloo rendezvous the timed run uses, the ranks' numbers are summed "
                          "and rank 0 prints one JSON line; tests/test_dp_cpu.py drives the self-launcher through this on CPU-only boxes")
@@ -253,7 +256,7 @@ def main():
         dist.barrier()
     if not a.no_layer_events:
         if model.use_plan:  # HIP event pairs around the family's launches, recorded by the native plan on the stream it issues to
-            model.plan_profile_begin(a.batch, a.size, set(fam))
+            model.plan_profile_begin(a.batch, a.size, set(fam), every=a.event_every)
         else:               # AY_USE_PLAN=0: the per-layer walk brackets the same launches itself
             model.profile_layers = set(fam)
             model.profile_events = []
@@ -273,10 +276,11 @@ def main():
     events = []
     if not a.no_layer_events and model.use_plan:
         per_op, n_fwd = model.plan_profile_end(a.batch, a.size)
-        assert n_fwd == a.steps
+        assert n_fwd == (a.steps + a.event_every - 1) // a.event_every   # the forwards that carried event pairs
         famset = set(fam)
         events = [ms for layer, kind, ms in per_op if layer in famset]   # per family launch: ms summed over the timed steps
     elif not a.no_layer_events:
+        n_fwd = a.steps
         by_layer = {}
         for layer, s, e in model.profile_events:
             by_layer[layer] = by_layer.get(layer, 0.0) + s.elapsed_time(e)
@@ -331,8 +335,8 @@ def main():
     if rank == 0:
         if events:
             ms = sum(events)
-            launches = len(events) * a.steps
-            achieved = fam_flops * a.steps / (ms * 1e-3) / 1e12
+            launches = len(events) * n_fwd                      # launches that were bracketed by an event pair
+            achieved = fam_flops * n_fwd / (ms * 1e-3) / 1e12
             traffic, traffic_note = load_traffic(a, os.path.basename(a.traffic_json), "conv3x3s1_bn128_bytes_per_launch")
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -340,8 +344,10 @@ def main():
                 "kernel": f"ay::conv3x3_m16_ring_kernel<res|nores, {'F16' if a.dtype == 'fp16' else 'Bf16'}> (3x3 s1, 128 ch x 512 px tile, "
                           f"v_mfma_f32_16x16x32_{'f16' if a.dtype == 'fp16' else 'bf16'}, persistent LDS-DMA ring; "
                           "AY_M16=0: ay::conv_bf16_ring_kernel<3,1,128,2,4,16,32,1,2,...> on 32x32x16)",
-                "launches_per_step": launches // a.steps, "avg_launch_ms": round(ms / launches, 4),
-                "flops_per_launch": fam_flops / (launches // a.steps), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
+                "launches_per_step": launches // n_fwd, "avg_launch_ms": round(ms / launches, 4),
+                "flops_per_launch": fam_flops / (launches // n_fwd), "family_share_of_model_flops": round(fam_flops / total_flops, 3),
+                "timed_launches": launches, "launch_sample": f"HIP event pairs around every launch of the family on {n_fwd} of the {a.steps} timed steps "
+                                                             f"(every {a.event_every}th, inside the timed region, on the issue stream)",
             }
     # ---- the rest of BASELINE.json's metric in the same line: "train imgs/sec @1/2/4/8 GPU" (configs[2]: B=32 per GPU, 1024^2), and the
     # parity-grade fp32 path's tiles/s.  All GPU legs first, the host-heavy CPU baseline + parity legs last.  RCCL comes up only now
@@ -418,11 +424,15 @@ def measure_train(a, rank, world, dev, B, S, steps, warmup, group=None):
     barrier()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
-    if not a.no_layer_events:
-        model._train_prof = {"wgrad": [], "conv": []}   # HIP event pairs around the 3x3 family's launches (issue stream)
+    prof_acc = None if a.no_layer_events else {"wgrad": [], "conv": []}   # HIP event pairs around the 3x3 family's launches (issue stream),
+    n_prof = 0                                                            # on every a.event_every-th step of the timed region
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        on = prof_acc is not None and k % a.event_every == 0
+        model._train_prof = prof_acc if on else None
+        n_prof += int(on)
         losses.append(step())
+    model._train_prof = prof_acc
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -455,18 +465,19 @@ def measure_train(a, rank, world, dev, B, S, steps, warmup, group=None):
         fl_c = fl_w + sum(conv_flops(e, B, S) for e in fam if e["cin"] % 128 == 0)           # forward + the timed data gradients
         ms_w = sum(e0.elapsed_time(e1) for e0, e1 in prof["wgrad"])
         ms_c = sum(e0.elapsed_time(e1) for e0, e1 in prof["conv"])
-        ach_w = fl_w * steps / (ms_w * 1e-3) / 1e12
+        ach_w = fl_w * n_prof / (ms_w * 1e-3) / 1e12
         traffic, traffic_note = load_traffic(a, "traffic_train.json", "wgrad3x3_bytes_per_launch") if (B, S) == (32, 1024) else (None, "measured at B=32, 1024^2 only")
         result["roofline"] = {
             "bound": "mfma", "achieved": round(ach_w, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_w / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_note,
             "kernel": "ay::wgrad_bf16_kernel<3,1> (weight gradient of the 3x3 s1 family: the largest share of the step)",
-            "launches_per_step": len(prof["wgrad"]) // steps, "avg_launch_ms": round(ms_w / len(prof["wgrad"]), 4),
-            "flops_per_launch": fl_w / max(1, len(prof["wgrad"]) // steps),
-            "share_of_step": round(ms_w / steps / (1e3 * elapsed / steps), 3),
+            "launches_per_step": len(prof["wgrad"]) // n_prof, "avg_launch_ms": round(ms_w / len(prof["wgrad"]), 4),
+            "flops_per_launch": fl_w / max(1, len(prof["wgrad"]) // n_prof),
+            "share_of_step": round(ms_w / n_prof / (1e3 * elapsed / steps), 3),
+            "launch_sample": f"HIP event pairs on {n_prof} of the {steps} timed steps (every {a.event_every}th)",
             "conv_family": {"kernel": "ay::conv3x3_m16_ring_kernel (forward + data gradient of the same layers; grids below 16 rows or canvas-tiled ones -- the 416-px maps -- run on ay::conv_bf16_ring_kernel<3,1,128,...>)",
-                            "achieved": round(fl_c * steps / (ms_c * 1e-3) / 1e12, 1), "frac": round(fl_c * steps / (ms_c * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                            "launches_per_step": len(prof["conv"]) // steps, "share_of_step": round(ms_c / steps / (1e3 * elapsed / steps), 3)},
+                            "achieved": round(fl_c * n_prof / (ms_c * 1e-3) / 1e12, 1), "frac": round(fl_c * n_prof / (ms_c * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                            "launches_per_step": len(prof["conv"]) // n_prof, "share_of_step": round(ms_c / n_prof / (1e3 * elapsed / steps), 3)},
         }
     # hand the step's memory back: the default mode goes on to other legs
     model._train_ctx = {}
