@@ -151,6 +151,38 @@ def test_nms_golden(golden_dir, dev, name):
         np.testing.assert_array_equal(got[:, 4:], z[f"rows{b}"][:, 4:])    # conf / cls columns untouched
 
 
+@pytest.mark.parametrize("case", [(2048, [900, 1024, 17, 0], 6, 51), (1500, [640, 1000], 13, 52), (4096, [1023, 1], 80, 53), (600, [600], 5, 54)],
+                         ids=lambda c: "N%d_C%d" % (c[0], c[2]))
+def test_nms_class_partitions_vs_oracle(dev, case):
+    """The LDS path of `nms_merge_kernel` scans four class partitions (class & 3) on four wavefronts.  With more than four classes a
+    partition holds several classes (the same-class test inside the scan keeps them apart), with 5 or 13 they are uneven, with 80 a
+    partition interleaves twenty; images at exactly 1 024 candidates (the path's limit), a single candidate, none; `max_det` smaller
+    than the number of heads (the first max_det heads in score order are kept, the count says how many there were): indices, rows and
+    counts against the CPU oracle."""
+    N, cands, Cn, seed = case
+    pred = gc.nms_prediction(N, cands, Cn, seed, conf_thres=0.5)
+    o_rows, o_keep, _ = bo.non_max_suppression(pred.copy(), 0.5, 0.4)
+    res = ay.non_max_suppression(torch.from_numpy(pred.copy()).to(dev), 0.5, 0.4)
+    for b in range(len(cands)):
+        if o_rows[b] is None:
+            assert res[b] is None
+            continue
+        np.testing.assert_array_equal(res.keep_idx[b], o_keep[b])
+        close(res[b].cpu().numpy(), o_rows[b], 1e-5)
+        assert int(res.cand_count[b]) == cands[b]
+    # truncation: the fused device call with room for 8 heads per image
+    from amyloid_yolo_paper_amd.utils import nms_device
+    rows, keep, count, cand = nms_device(torch.from_numpy(pred.copy()).to(dev), 0.5, 0.4, 8, slot=3)
+    rows, keep, count = rows.cpu().numpy(), keep.cpu().numpy(), count.cpu().numpy()
+    for b in range(len(cands)):
+        n_all = 0 if o_rows[b] is None else len(o_keep[b])
+        assert int(count[b]) == n_all
+        k = min(n_all, 8)
+        if k:
+            np.testing.assert_array_equal(keep[b, :k], o_keep[b][:k])
+            close(rows[b, :k], o_rows[b][:k], 1e-5)
+
+
 def test_nms_device_tensor_and_large(dev):
     """device-resident input; 20k candidates exercises the workspace (non-LDS) sort path."""
     pred = gc.nms_prediction(30000, [20000], 3, 41, conf_thres=0.3)
