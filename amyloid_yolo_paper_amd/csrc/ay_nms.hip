@@ -17,6 +17,8 @@
 // IoU uses the reference's +1-pixel rule and operation order (fp32, no contraction) so `> nms_thres`
 // decisions are bit-identical; only the merged corners (a sum whose order the reference does not fix)
 // differ in the last bits.
+#include <stdlib.h>
+
 #include "ay_common.h"
 
 namespace ay {
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
                                                         unsigned long long* keys, float* cand, int cap,
                                                         const int* __restrict__ cand_count, int max_det,
                                                         float* __restrict__ out_rows, int* __restrict__ keep_idx,
-                                                        int* __restrict__ count, unsigned long long* alive_ws) {
+                                                        int* __restrict__ count, unsigned long long* alive_ws, int mid_limit) {
     __shared__ unsigned long long skeys[NMS_LDS_KEYS];
     __shared__ float fc[8][NMS_FAST];  // fast path: x1, y1, x2, y2, conf, class, class conf, original row (as int) in sorted order
     __shared__ unsigned long long head_s[NMS_PARTS][NMS_WORDS];  // fast path: head bitmap per class partition, then ([0]) their union
@@ -144,6 +146,7 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
         if (tid == 0) count[b] = 0;
         return;
     }
+    if (n > NMS_FAST && n <= mid_limit) return;   // nms_merge_mid_kernel's image (launched behind this kernel)
     unsigned long long* kb = keys + (size_t)b * cap;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
@@ -383,6 +386,151 @@ __global__ void __launch_bounds__(256) nms_merge_kernel(const float* __restrict_
     if (lane == 0) count[b] = kept;  // > max_det means the caller's buffers were too small (rows were dropped)
 }
 
+// ---- 1 025 .. 4 096 candidates per image: the same four-partition scan with everything in LDS (128 KiB: this workgroup has a CU to
+// itself, which the larger candidate sets of 2048^2 crops can afford; the workspace scan below it took 8 / 65 ms per image at 2 000 /
+// 4 000 candidates, an L2 round trip per alive word and head).  A partition's alive words live one per LANE (lane w = word w, 64 words);
+// per head the wave walks the non-empty words only (ballot over the lanes), fetches a word with v_readlane, and the lane that owns the
+// word updates it.  Members meet the lanes in the order of the one-wavefront scan (ascending word, lane = position in the word).
+constexpr int NMS_MID = 4096;
+constexpr int NMS_MID_WORDS = NMS_MID / 64;
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(256) nms_merge_mid_kernel(const float* __restrict__ pred, int N, int C, float nms_thres,
+                                                            const unsigned long long* __restrict__ keys, int cap,
+                                                            const int* __restrict__ cand_count, int max_det, float* __restrict__ out_rows,
+                                                            int* __restrict__ keep_idx, int* __restrict__ count) {
+    __shared__ unsigned long long skeys[NMS_MID];
+    __shared__ float fc[6][NMS_MID];   // x1, y1, x2, y2, conf, class in sorted order (class conf and row come back from pred / the keys)
+    __shared__ unsigned long long head_s[NMS_PARTS][NMS_MID_WORDS];
+    __shared__ int wpre[NMS_MID_WORDS];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int K = 5 + C;
+    const int n = min(cand_count[b], N);
+    if (n <= NMS_FAST || n > NMS_MID) return;   // nms_merge_kernel's images (LDS path up to 1 024, workspace scan beyond 4 096)
+    const unsigned long long* kb = keys + (size_t)b * cap;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) skeys[i] = i < n ? kb[i] : ~0ull;
+    for (int i = tid; i < NMS_PARTS * NMS_MID_WORDS; i += 256) (&head_s[0][0])[i] = 0ull;
+    __syncthreads();
+    bitonic_sort(skeys, np2, tid, 256);
+    const float* pb = pred + (size_t)b * N * K;
+    for (int i = tid; i < n; i += 256) {
+        const int r = (int)(unsigned)(skeys[i] & 0xffffffffu);
+        const float* p = pb + (size_t)r * K;
+        float mc = p[5];
+        int arg = 0;
+        for (int k = 1; k < C; ++k) {
+            const float v = p[5 + k];
+            if (v > mc) {  // first maximum wins, like torch.max
+                mc = v;
+                arg = k;
+            }
+        }
+        fc[0][i] = p[0];
+        fc[1][i] = p[1];
+        fc[2][i] = p[2];
+        fc[3][i] = p[3];
+        fc[4][i] = p[4];
+        fc[5][i] = (float)arg;
+    }
+    __syncthreads();
+    const int nwords = (n + 63) >> 6;
+    const int lane = tid & 63;
+    const int part = tid >> 6;
+    // lane w: alive word w of this partition
+    unsigned long long al = 0ull;
+    for (int w = 0; w < nwords; ++w) {
+        const int j = w * 64 + lane;
+        const unsigned long long m = __ballot(j < n && (((int)fc[5][min(j, NMS_MID - 1)]) & 3) == part);
+        if (lane == w) al = m;
+    }
+    while (true) {
+        unsigned long long nz = __ballot(al != 0ull);   // non-empty words
+        if (nz == 0ull) break;
+        const int w0 = __builtin_ctzll(nz);
+        const int head = w0 * 64 + __builtin_ctzll(readlane64(al, w0));
+        const float hx1 = fc[0][head], hy1 = fc[1][head], hx2 = fc[2][head], hy2 = fc[3][head], hcls = fc[5][head];
+        float sw = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        while (nz != 0ull) {
+            const int w = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
+            const unsigned long long a = readlane64(al, w);
+            const int j = w * 64 + lane;
+            bool member = (j == head);  // the head always leaves the set (also when its IoU is NaN)
+            if ((a >> lane) & 1ull) {
+                const float x1 = fc[0][j], y1 = fc[1][j], x2 = fc[2][j], y2 = fc[3][j];
+                const float iou = iou_p1(hx1, hy1, hx2, hy2, x1, y1, x2, y2);
+                member = member || ((iou > nms_thres) && (fc[5][j] == hcls));
+                if (member) {
+                    const float wgt = fc[4][j];
+                    sw += wgt;
+                    s0 += wgt * x1;
+                    s1 += wgt * y1;
+                    s2 += wgt * x2;
+                    s3 += wgt * y2;
+                }
+            }
+            const unsigned long long m = __ballot(member);
+            if (lane == w) al = a & ~m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sw += __shfl_xor(sw, off);
+            s0 += __shfl_xor(s0, off);
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+            s3 += __shfl_xor(s3, off);
+        }
+        if (lane == 0) {   // the head's own entry is never read again: it carries the merged corners to the emission pass
+            fc[0][head] = s0 / sw;
+            fc[1][head] = s1 / sw;
+            fc[2][head] = s2 / sw;
+            fc[3][head] = s3 / sw;
+            head_s[part][head >> 6] |= 1ull << (head & 63);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < NMS_MID_WORDS) {
+        unsigned long long m = 0ull;
+        for (int k = 0; k < NMS_PARTS; ++k) m |= head_s[k][tid];
+        head_s[0][tid] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < NMS_MID_WORDS; ++w) {
+            wpre[w] = acc;
+            acc += __builtin_popcountll(head_s[0][w]);
+        }
+        count[b] = acc;  // > max_det means the caller's buffers were too small (rows were dropped)
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long m = head_s[0][i >> 6];
+        if (!((m >> (i & 63)) & 1ull)) continue;
+        const int rank = wpre[i >> 6] + __builtin_popcountll(m & ((1ull << (i & 63)) - 1ull));
+        if (rank >= max_det) continue;
+        const int r = (int)(unsigned)(skeys[i] & 0xffffffffu);
+        const int cl = (int)fc[5][i];
+        float* o = out_rows + ((size_t)b * max_det + rank) * 7;
+        o[0] = fc[0][i];
+        o[1] = fc[1][i];
+        o[2] = fc[2][i];
+        o[3] = fc[3][i];
+        o[4] = fc[4][i];
+        o[5] = pb[(size_t)r * K + 5 + cl];
+        o[6] = fc[5][i];
+        keep_idx[(size_t)b * max_det + rank] = r;
+    }
+}
+
 }  // namespace ay
 
 using namespace ay;
@@ -430,9 +578,18 @@ extern "C" int ay_nms_sort_merge(const float* pred, int batch, int n_rows, int n
     unsigned long long* keys = (unsigned long long*)workspace;
     float* cand = (float*)((char*)workspace + (size_t)batch * cap * 8);
     unsigned long long* alive_ws = (unsigned long long*)((char*)workspace + (size_t)batch * cap * (8 + 8 * 4));
+    // images with 1 025 .. 4 096 candidates go to the all-LDS kernel behind it (it returns at once for the others); AY_NMS_MID=0: the
+    // workspace scan takes them, as before round 4
+    static const int mid_on = getenv("AY_NMS_MID") ? atoi(getenv("AY_NMS_MID")) : 1;
+    const int mid_limit = (mid_on && n_rows > NMS_FAST) ? NMS_MID : NMS_FAST;
     hipLaunchKernelGGL(nms_merge_kernel, dim3(batch), dim3(256), 0, S(stream), pred, n_rows, num_classes, nms_thres, keys, cand, cap,
-                       cand_count, max_det, out_rows, keep_idx, count, alive_ws);
+                       cand_count, max_det, out_rows, keep_idx, count, alive_ws, mid_limit);
     AY_CHECK_LAUNCH("nms_merge_kernel");
+    if (mid_limit > NMS_FAST) {
+        hipLaunchKernelGGL(nms_merge_mid_kernel, dim3(batch), dim3(256), 0, S(stream), pred, n_rows, num_classes, nms_thres, keys, cap, cand_count,
+                           max_det, out_rows, keep_idx, count);
+        AY_CHECK_LAUNCH("nms_merge_mid_kernel");
+    }
     return AY_OK;
 }
 

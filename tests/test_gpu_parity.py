@@ -151,14 +151,16 @@ def test_nms_golden(golden_dir, dev, name):
         np.testing.assert_array_equal(got[:, 4:], z[f"rows{b}"][:, 4:])    # conf / cls columns untouched
 
 
-@pytest.mark.parametrize("case", [(2048, [900, 1024, 17, 0], 6, 51), (1500, [640, 1000], 13, 52), (4096, [1023, 1], 80, 53), (600, [600], 5, 54)],
+@pytest.mark.parametrize("case", [(2048, [900, 1024, 17, 0], 6, 51), (1500, [640, 1000], 13, 52), (4096, [1023, 1], 80, 53), (600, [600], 5, 54),
+                                  (8192, [4096, 1025, 2500, 300], 3, 55), (8192, [4097, 3000], 6, 56), (6000, [2047, 2048, 2049], 13, 57)],
                          ids=lambda c: "N%d_C%d" % (c[0], c[2]))
 def test_nms_class_partitions_vs_oracle(dev, case):
     """The LDS path of `nms_merge_kernel` scans four class partitions (class & 3) on four wavefronts.  With more than four classes a
     partition holds several classes (the same-class test inside the scan keeps them apart), with 5 or 13 they are uneven, with 80 a
     partition interleaves twenty; images at exactly 1 024 candidates (the path's limit), a single candidate, none; `max_det` smaller
     than the number of heads (the first max_det heads in score order are kept, the count says how many there were): indices, rows and
-    counts against the CPU oracle."""
+    counts against the CPU oracle.  Images with 1 025 .. 4 096 candidates take `nms_merge_mid_kernel` (the same scan, all in LDS, alive
+    words one per lane), 4 097 and more the workspace scan: mixed in one batch here."""
     N, cands, Cn, seed = case
     pred = gc.nms_prediction(N, cands, Cn, seed, conf_thres=0.5)
     o_rows, o_keep, _ = bo.non_max_suppression(pred.copy(), 0.5, 0.4)
