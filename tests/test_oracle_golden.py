@@ -219,3 +219,17 @@ def test_giou_closed_form_vectors(golden_dir):
     def cxcywh(b):
         return torch.tensor(np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1))
     np.testing.assert_allclose(giou_cxcywh(cxcywh(b1), cxcywh(b2)).numpy(), want, rtol=0, atol=2e-7)
+
+
+def test_layer_modes_override_the_storage_type_per_layer(tmp_cfg_dir):
+    """`OracleDarknet.forward(layer_modes=...)` (oracle/parity_sweep.py): an all-fp32 plan is the default forward bit for bit, an all-bf16
+    / all-fp16 plan is `mode="bf16"` / `mode="fp16"` bit for bit, and a split plan differs from both"""
+    m, _ = _oracle_model(3, tmp_cfg_dir)
+    x = torch.from_numpy(gc.model_inputs(64, 1, 0))
+    with torch.no_grad():
+        base = m.forward(x)
+        assert torch.equal(m.forward(x, layer_modes=lambda i: "fp32"), base)
+        for mode in ("bf16", "fp16"):
+            assert torch.equal(m.forward(x, layer_modes=lambda i, mode=mode: mode), m.forward(x, mode=mode))
+        split = m.forward(x, layer_modes=lambda i: "bf16" if i <= 36 else "fp16")
+        assert not torch.equal(split, m.forward(x, mode="bf16")) and not torch.equal(split, m.forward(x, mode="fp16"))
