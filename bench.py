@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no_other_dtype", action="store_true", help="default mode: skip the timing of the other 16-bit storage type")
     ap.add_argument("--no_train_leg", action="store_true", help="default mode: skip the appended training measurement (configs[2])")
     ap.add_argument("--no_fp32_leg", action="store_true", help="default mode: skip the appended fp32 parity-path measurement")
+    ap.add_argument("--no_pipelined_leg", action="store_true", help="default mode: skip the appended two-batches-in-flight measurement")
     ap.add_argument("--leg_train_size", type=int, default=1024, help="tile side of the appended training measurement (configs[2])")
     ap.add_argument("--leg_train_steps", type=int, default=10)
     ap.add_argument("--fp32_batch", type=int, default=8)
@@ -315,6 +316,39 @@ def main():
             el_o = float(t.item())
         other_line = {"dtype": other, "value": round(a.gpus * a.batch * a.steps / el_o, 2), "unit": "tiles/s", "ms_per_step": round(1e3 * el_o / a.steps, 3)}
         other_model, model = model, main_model
+    # The same step with TWO batches in flight: two model instances (own arenas and output slots) on two streams, steps alternating
+    # between them, each stream running its forward and its merge-NMS back to back.  A persistent launch takes every CU, so nothing of
+    # one batch hides under the other except the tail of a launch (workgroups that have run out of items), the ramp of the next one and
+    # the gaps in between -- which is what this leg measures.  It is reported beside the headline, never as `value`: once launches of
+    # two streams overlap, the per-launch HIP-event times the roofline is built from include the other stream's work.
+    pipelined = None
+    if not a.no_pipelined_leg and a.gpus == 1:
+        try:
+            pipes = [(model, torch.cuda.Stream(device=dev), 0), (make_model(a.dtype), torch.cuda.Stream(device=dev), 2)]
+            torch.cuda.synchronize()
+
+            def pstep(k):
+                m_, st_, slot_ = pipes[k & 1]
+                with torch.cuda.stream(st_):
+                    o_ = m_.forward_device(x, out_slot=0)
+                    return nms_device(o_, a.conf_thres, a.nms_thres, a.max_det, slot_)
+
+            for k in range(2 * max(1, a.warmup // 2)):
+                pres = pstep(k)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for k in range(a.steps):
+                pres = pstep(k)
+            torch.cuda.synchronize()
+            el_p = time.perf_counter() - tp0
+            same = bool(torch.equal(pres[2], count))
+            pipelined = {"value": round(a.batch * a.steps / el_p, 2), "unit": "tiles/s", "ms_per_step": round(1e3 * el_p / a.steps, 3), "dtype": a.dtype,
+                         "batches_in_flight": 2, "same_detection_counts_as_the_headline_step": same,
+                         "what": "two batches in flight on two streams (two model instances, forward + merge-NMS back to back on each): the launch tails, "
+                                 "ramps and gaps of one batch filled by the other; not the headline because overlapping launches void per-launch event times"}
+            del pipes, pres
+        except Exception as exc:
+            pipelined = {"error": f"{type(exc).__name__}: {exc}"}
     assert cnt.max() <= a.max_det, f"max_det {a.max_det} too small: {cnt.max()} cluster heads"
     raw_ok = bool(torch.isfinite(rows[0, : max(int(cnt[0]), 1)]).all())
     assert raw_ok, "non-finite detections"
@@ -332,6 +366,8 @@ def main():
     }
     if other_line is not None:
         result["other_dtype"] = other_line
+    if pipelined is not None:
+        result["pipelined"] = pipelined
     if rank == 0:
         if events:
             ms = sum(events)

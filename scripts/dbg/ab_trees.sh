@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 for rep in 1 2 3; do
   for d in "$@"; do
-    r=$(cd $d && timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_other_dtype --no_fp32_leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('infer', d['ms_per_step'], d['value'], d['roofline']['frac'], '| train', d['train']['ms_per_step'], d['train']['value'])")
+    r=$(cd $d && timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_other_dtype --no_fp32_leg --no_pipelined_leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('infer', d['ms_per_step'], d['value'], d['roofline']['frac'], '| train', d['train']['ms_per_step'], d['train']['value'])")
     echo "$d -> $r"
   done
 done

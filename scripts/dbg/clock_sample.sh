@@ -3,7 +3,7 @@
 # (the question: same kernels, same instruction counts -- why is the half-precision path ~4 % slower?  DESIGN.md section 2)
 DT=$1
 OUT=$2
-python bench.py --dtype $DT --steps 300 --warmup 20 --no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg > $OUT.bench 2>&1 &
+python bench.py --dtype $DT --steps 300 --warmup 20 --no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg --no_pipelined_leg > $OUT.bench 2>&1 &
 PID=$!
 sleep 6   # import + warm-up
 : > $OUT.smi

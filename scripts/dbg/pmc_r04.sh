@@ -2,7 +2,7 @@
 # SQ / TCP counter passes over the inference step (B=64, 1024^2, bf16): usage scripts/dbg/pmc_r04.sh TAG -> gpurun_out/r04_pmc_sq_TAG.txt
 export TMPDIR=/tmp
 TAG=${1:-v1}
-INF="--steps 1 --warmup 1 --no_cpu_baseline --no_layer_events --no_other_dtype --no_train_leg --no_fp32_leg"
+INF="--steps 1 --warmup 1 --no_cpu_baseline --no_layer_events --no_other_dtype --no_train_leg --no_fp32_leg --no_pipelined_leg"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES" \

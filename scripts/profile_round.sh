@@ -5,7 +5,7 @@ set -e
 export TMPDIR=/tmp
 TAG=$1
 R=${ROUND:-r03}
-INF="--no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg --dtype ${AY_PROFILE_DTYPE:-bf16}"
+INF="--no_cpu_baseline --no_other_dtype --no_train_leg --no_fp32_leg --no_pipelined_leg --dtype ${AY_PROFILE_DTYPE:-bf16}"
 rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write
 # ---- inference (the timed dtype of bench.py's default line: bf16; AY_PROFILE_DTYPE=fp16 profiles the other one)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 5 --warmup 2 $INF > gpurun_out/bench_kt_$TAG.log 2>&1
@@ -18,7 +18,7 @@ python scripts/hbm_traffic.py gpurun_out/prof_fetch gpurun_out/prof_write --json
 tail -3 gpurun_out/${R}_hbm_traffic_$TAG.txt
 rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write
 # ---- the fp32 parity path (B=8)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_other_dtype --no_train_leg > gpurun_out/bench_kt_fp32_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_other_dtype --no_train_leg --no_pipelined_leg > gpurun_out/bench_kt_fp32_$TAG.log 2>&1
 cp gpurun_out/prof_kt/*/*_kernel_stats.csv gpurun_out/${R}_bench_fp32leg_kernel_stats_$TAG.csv
 rm -rf gpurun_out/prof_kt
 echo "fp32 leg kernel trace done"
