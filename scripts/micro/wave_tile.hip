@@ -117,6 +117,7 @@ int main() {
     hipMemcpyToSymbol(HIP_SYMBOL(g_random), &one, sizeof(int));
     run<8, 2, 4>("A' = A with random operands", out);
     run<8, 2, 2>("C' = C with random operands", out);
+    run<4, 4, 4>("B' = B with random operands", out);
     int zero = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_random), &zero, sizeof(int));
     run<4, 4, 4>("B 4 waves 128x128", out);
